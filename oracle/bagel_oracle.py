@@ -1,0 +1,569 @@
+"""CPU restatement of BAGEL's packed flow-matching denoise step (TEST INFRASTRUCTURE).
+
+This file is a checker, not a product path: only ``tests/``, the smoke check and
+the benchmark's CPU-baseline leg may import it.  It restates, in plain PyTorch on
+the CPU, the arithmetic the reference performs for image generation, following the
+reference's rounding points (bf16 storage, fp32 internals) one by one.  Every
+function cites the reference lines it follows.  It is pinned against outputs of
+the reference itself (tests/golden/*.safetensors, produced by
+tests/golden/make_golden.py which imports the reference in the authoring
+container).
+
+The third-party ``flash_attn_varlen_func`` (pinned ``flash_attn==2.5.8`` in the
+reference's requirements.txt:16, source absent) is restated by its published
+definition: per-sample softmax(QK^T/sqrt(D))V with grouped KV heads.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+BF16 = torch.bfloat16
+
+
+class exact_arithmetic:
+    """Context manager: evaluate the same graph with every bf16 rounding point turned into fp32.
+
+    Used with an fp32 copy of the weights to obtain the exact-arithmetic answer, against which
+    the reference's own bf16 rounding noise is measured (the "noise floor" of a scenario).
+    """
+
+    def __enter__(self):
+        global BF16
+        self._saved = BF16
+        BF16 = torch.float32
+        return self
+
+    def __exit__(self, *exc):
+        global BF16
+        BF16 = self._saved
+        return False
+
+
+# ----------------------------------------------------------------------------
+# primitives
+# ----------------------------------------------------------------------------
+def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    """Qwen2RMSNorm.forward, modeling/qwen2/modeling_qwen2.py:54-59."""
+    in_dtype = x.dtype
+    h = x.to(torch.float32)
+    var = h.pow(2).mean(-1, keepdim=True)
+    h = h * torch.rsqrt(var + eps)
+    return w * h.to(in_dtype)
+
+
+def rotary_cos_sin(position_ids: torch.Tensor, head_dim: int, theta: float,
+                   dtype=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Qwen2RotaryEmbedding.forward, modeling_qwen2.py:130-150 (default rope, scaling 1.0).
+
+    inv_freq = 1/theta^(arange(0,D,2)/D); cos/sin are rounded to the activation dtype.
+    """
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    freqs = (inv_freq[None, :, None].float() @ position_ids[None, None, :].float()).transpose(1, 2)[0]
+    emb = torch.cat((freqs, freqs), dim=-1)
+    dtype = BF16 if dtype is None else dtype
+    return emb.cos().to(dtype), emb.sin().to(dtype)
+
+
+def rotate_half(x: torch.Tensor) -> torch.Tensor:
+    """modeling_qwen2.py:154-158."""
+    x1 = x[..., : x.shape[-1] // 2]
+    x2 = x[..., x.shape[-1] // 2:]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+def apply_rope(q, k, cos, sin):
+    """apply_rotary_pos_emb with unsqueeze_dim=1, modeling_qwen2.py:162-186."""
+    cos = cos.unsqueeze(1)
+    sin = sin.unsqueeze(1)
+    return (q * cos) + (rotate_half(q) * sin), (k * cos) + (rotate_half(k) * sin)
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.Linear under bf16 autocast: operands cast to bf16, fp32 accumulate, bf16 result."""
+    return F.linear(x.to(BF16), w.to(BF16), None if b is None else b.to(BF16))
+
+
+def mlp(x, p: Dict[str, torch.Tensor], prefix: str) -> torch.Tensor:
+    """Qwen2MLP.forward, modeling_qwen2.py:200-201 (silu)."""
+    g = linear(x, p[prefix + "gate_proj.weight"])
+    u = linear(x, p[prefix + "up_proj.weight"])
+    return linear(F.silu(g) * u, p[prefix + "down_proj.weight"])
+
+
+def varlen_attention(q, k, v, q_lens: Sequence[int], k_lens: Sequence[int], causal: bool) -> torch.Tensor:
+    """Definition of flash_attn_varlen_func as called at qwen2_navit.py:590-599.
+
+    q [sum(q_lens), Hq, D], k/v [sum(k_lens), Hkv, D]; scale 1/sqrt(D); with
+    ``causal`` the mask is aligned to the bottom-right corner (flash-attn >= 2.1).
+    Follows the published FlashAttention-2 arithmetic: fp32 scores and softmax
+    statistics, probabilities rounded to the input dtype before the P.V product,
+    fp32 accumulation, normalisation by the fp32 row sum, result in the input dtype.
+    """
+    Hq, Hkv = q.shape[1], k.shape[1]
+    rep = Hq // Hkv
+    outs = []
+    qo = ko = 0
+    for lq, lk in zip(q_lens, k_lens):
+        qs = q[qo:qo + lq].transpose(0, 1).float()            # [Hq, lq, D]
+        ks = k[ko:ko + lk].transpose(0, 1).float().repeat_interleave(rep, dim=0)
+        vs = v[ko:ko + lk].transpose(0, 1).float().repeat_interleave(rep, dim=0)
+        s = qs @ ks.transpose(1, 2) / math.sqrt(q.shape[-1])
+        if causal:
+            i = torch.arange(lq)[:, None]
+            j = torch.arange(lk)[None, :]
+            s = s.masked_fill(j > i + (lk - lq), float("-inf"))
+        pexp = torch.exp(s - s.max(dim=-1, keepdim=True).values)
+        o = (pexp.to(q.dtype).float() @ vs) / pexp.sum(dim=-1, keepdim=True)
+        outs.append(o.transpose(0, 1).to(q.dtype))
+        qo += lq
+        ko += lk
+    return torch.cat(outs, dim=0)
+
+
+class Cache:
+    """NaiveCache, qwen2_navit.py:214-228."""
+
+    def __init__(self, num_layers: int):
+        self.key_cache = {k: None for k in range(num_layers)}
+        self.value_cache = {k: None for k in range(num_layers)}
+
+    @property
+    def num_layers(self):
+        return len(self.key_cache)
+
+    @property
+    def seq_lens(self):
+        return 0 if self.key_cache[0] is None else self.key_cache[0].shape[0]
+
+
+# ----------------------------------------------------------------------------
+# MoT layer and model forward
+# ----------------------------------------------------------------------------
+def attention_inference(p, pre, dims, layer_idx, x, query_lens, cos, sin, packed_query_indexes,
+                        past: Optional[Cache], key_values_lens, packed_key_value_indexes,
+                        update_past_key_values, is_causal, mode, vae_idx, text_idx):
+    """PackedAttentionMoT.forward_inference, qwen2_navit.py:510-611."""
+    Hq, Hkv, D, eps = dims.num_heads, dims.num_kv_heads, dims.head_dim, dims.rms_norm_eps
+    a = pre + "self_attn."
+    if mode == "und":
+        q = linear(x, p[a + "q_proj.weight"], p[a + "q_proj.bias"]).view(-1, Hq, D)
+        k = linear(x, p[a + "k_proj.weight"], p[a + "k_proj.bias"]).view(-1, Hkv, D)
+        v = linear(x, p[a + "v_proj.weight"], p[a + "v_proj.bias"]).view(-1, Hkv, D)
+        q = rms_norm(q, p[a + "q_norm.weight"], eps)
+        k = rms_norm(k, p[a + "k_norm.weight"], eps)
+    else:
+        x = x.to(BF16)
+        n = x.shape[0]
+        q = x.new_zeros((n, Hq * D))
+        k = x.new_zeros((n, Hkv * D))
+        v = x.new_zeros((n, Hkv * D))
+        xt, xv = x[text_idx], x[vae_idx]
+        q[text_idx] = linear(xt, p[a + "q_proj.weight"], p[a + "q_proj.bias"])
+        q[vae_idx] = linear(xv, p[a + "q_proj_moe_gen.weight"], p[a + "q_proj_moe_gen.bias"])
+        k[text_idx] = linear(xt, p[a + "k_proj.weight"], p[a + "k_proj.bias"])
+        k[vae_idx] = linear(xv, p[a + "k_proj_moe_gen.weight"], p[a + "k_proj_moe_gen.bias"])
+        v[text_idx] = linear(xt, p[a + "v_proj.weight"], p[a + "v_proj.bias"])
+        v[vae_idx] = linear(xv, p[a + "v_proj_moe_gen.weight"], p[a + "v_proj_moe_gen.bias"])
+        q = q.view(-1, Hq, D).to(torch.float32)
+        k = k.view(-1, Hkv, D).to(torch.float32)
+        v = v.view(-1, Hkv, D)
+        q[text_idx] = rms_norm(q[text_idx], p[a + "q_norm.weight"], eps)
+        q[vae_idx] = rms_norm(q[vae_idx], p[a + "q_norm_moe_gen.weight"], eps)
+        k[text_idx] = rms_norm(k[text_idx], p[a + "k_norm.weight"], eps)
+        k[vae_idx] = rms_norm(k[vae_idx], p[a + "k_norm_moe_gen.weight"], eps)
+
+    q, k = apply_rope(q, k, cos, sin)
+    q, k, v = q.to(BF16), k.to(BF16), v.to(BF16)
+
+    q_lens = [int(t) for t in query_lens]
+    if past is not None and past.key_cache[layer_idx] is not None:
+        pk, pv = past.key_cache[layer_idx], past.value_cache[layer_idx]
+        kv_lens = [int(t) for t in key_values_lens]
+        total = sum(q_lens) + sum(kv_lens)
+        mk = pk.new_zeros((total, Hkv, D))
+        mv = pk.new_zeros((total, Hkv, D))
+        mk[packed_query_indexes] = k
+        mk[packed_key_value_indexes] = pk
+        mv[packed_query_indexes] = v
+        mv[packed_key_value_indexes] = pv
+        k_lens = [a_ + b_ for a_, b_ in zip(kv_lens, q_lens)]
+    else:
+        mk, mv = k, v
+        k_lens = q_lens
+
+    o = varlen_attention(q, mk, mv, q_lens, k_lens, is_causal).reshape(-1, Hq * D)
+    if mode == "und":
+        o = linear(o, p[a + "o_proj.weight"])
+    else:
+        o2 = o.clone()
+        o2[text_idx] = linear(o[text_idx], p[a + "o_proj.weight"])
+        o2[vae_idx] = linear(o[vae_idx], p[a + "o_proj_moe_gen.weight"])
+        o = o2
+    if update_past_key_values:
+        past.key_cache[layer_idx] = mk
+        past.value_cache[layer_idx] = mv
+    return o, past
+
+
+def layer_inference(p, dims, layer_idx, x, query_lens, cos, sin, packed_query_indexes, past,
+                    key_values_lens, packed_key_value_indexes, update_past_key_values, is_causal,
+                    mode, vae_idx, text_idx):
+    """Qwen2MoTDecoderLayer.forward_inference, qwen2_navit.py:771-845 (TaylorSeer off)."""
+    pre = f"language_model.model.layers.{layer_idx}."
+    eps = dims.rms_norm_eps
+    residual = x
+    if mode == "und":
+        h = rms_norm(x, p[pre + "input_layernorm.weight"], eps)
+    else:
+        h = torch.zeros_like(x)
+        h[text_idx] = rms_norm(x[text_idx], p[pre + "input_layernorm.weight"], eps)
+        h[vae_idx] = rms_norm(x[vae_idx], p[pre + "input_layernorm_moe_gen.weight"], eps)
+    h, past = attention_inference(p, pre, dims, layer_idx, h, query_lens, cos, sin, packed_query_indexes,
+                                  past, key_values_lens, packed_key_value_indexes,
+                                  update_past_key_values, is_causal, mode, vae_idx, text_idx)
+    x = residual + h
+    residual = x
+    if mode == "und":
+        h = mlp(rms_norm(x, p[pre + "post_attention_layernorm.weight"], eps), p, pre + "mlp.")
+    else:
+        ht = rms_norm(x[text_idx], p[pre + "post_attention_layernorm.weight"], eps).to(BF16)
+        hv = rms_norm(x[vae_idx], p[pre + "post_attention_layernorm_moe_gen.weight"], eps).to(BF16)
+        h = torch.zeros_like(x).to(BF16)
+        h[text_idx] = mlp(ht, p, pre + "mlp.")
+        h[vae_idx] = mlp(hv, p, pre + "mlp_moe_gen.")
+    return residual + h, past
+
+
+def llm_forward_inference(p, dims, x, query_lens, packed_query_position_ids, packed_query_indexes,
+                          past=None, key_values_lens=None, packed_key_value_indexes=None,
+                          update_past_key_values=True, is_causal=True, mode="und",
+                          packed_vae_token_indexes=None, packed_text_indexes=None):
+    """Qwen2Model.forward_inference, qwen2_navit.py:1041-1115."""
+    cos, sin = rotary_cos_sin(packed_query_position_ids, dims.head_dim, dims.rope_theta, x.dtype)
+    for i in range(dims.num_layers):
+        x, past = layer_inference(p, dims, i, x, query_lens, cos, sin, packed_query_indexes, past,
+                                  key_values_lens, packed_key_value_indexes, update_past_key_values,
+                                  is_causal, mode, packed_vae_token_indexes, packed_text_indexes)
+    eps = dims.rms_norm_eps
+    if mode == "und":
+        x = rms_norm(x, p["language_model.model.norm.weight"], eps)
+    else:
+        y = torch.zeros_like(x)
+        y[packed_text_indexes] = rms_norm(x[packed_text_indexes], p["language_model.model.norm.weight"], eps)
+        y[packed_vae_token_indexes] = rms_norm(x[packed_vae_token_indexes],
+                                               p["language_model.model.norm_moe_gen.weight"], eps)
+        x = y
+    return x, past
+
+
+# ----------------------------------------------------------------------------
+# embedders
+# ----------------------------------------------------------------------------
+def timestep_embedding(t: torch.Tensor, dim: int, max_period: int = 10000) -> torch.Tensor:
+    """TimestepEmbedder.timestep_embedding, modeling/bagel/modeling_utils.py:88-107."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(t.dtype)
+    args = t[:, None] * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+def time_embedder(p, t: torch.Tensor, dim: int) -> torch.Tensor:
+    """TimestepEmbedder.forward, modeling_utils.py:109-112 (Linear, SiLU, Linear under bf16)."""
+    f = timestep_embedding(t, dim)
+    h = linear(f, p["time_embedder.mlp.0.weight"], p["time_embedder.mlp.0.bias"])
+    return linear(F.silu(h), p["time_embedder.mlp.2.weight"], p["time_embedder.mlp.2.bias"])
+
+
+def flattened_position_ids_extrapolate(img_h, img_w, patch_size, max_num_patches_per_side):
+    """data/data_utils.py:53-58."""
+    nh, nw = img_h // patch_size, img_w // patch_size
+    return (torch.arange(0, nh)[:, None] * max_num_patches_per_side + torch.arange(0, nw)).flatten()
+
+
+# ----------------------------------------------------------------------------
+# host index builders
+# ----------------------------------------------------------------------------
+def prepare_prompts(curr_kvlens, curr_rope, prompt_token_ids: List[List[int]], new_token_ids):
+    """Bagel.prepare_prompts, bagel.py:806-841, with the tokenizer call replaced by given ids."""
+    ids, pos, lens, idx, kvidx = [], [], [], [], []
+    curr = 0
+    newlens, new_rope = [], []
+    for toks, kvlen, rope in zip(prompt_token_ids, curr_kvlens, curr_rope):
+        kvidx.extend(range(curr, curr + kvlen))
+        curr += kvlen
+        t = [new_token_ids["bos_token_id"]] + list(toks) + [new_token_ids["eos_token_id"]]
+        lens.append(len(t))
+        ids.extend(t)
+        pos.extend(range(rope, rope + len(t)))
+        idx.extend(range(curr, curr + len(t)))
+        newlens.append(kvlen + len(t))
+        new_rope.append(rope + len(t))
+        curr += len(t)
+    gi = {
+        "text_token_lens": torch.tensor(lens, dtype=torch.int),
+        "packed_text_ids": torch.tensor(ids, dtype=torch.long),
+        "packed_text_position_ids": torch.tensor(pos, dtype=torch.long),
+        "packed_text_indexes": torch.tensor(idx, dtype=torch.long),
+        "packed_key_value_indexes": torch.tensor(kvidx, dtype=torch.long),
+        "key_values_lens": torch.tensor(curr_kvlens, dtype=torch.int),
+    }
+    return gi, newlens, new_rope
+
+
+def forward_cache_update_text(p, dims, past, packed_text_ids, packed_text_position_ids, text_token_lens,
+                              packed_text_indexes, packed_key_value_indexes, key_values_lens):
+    """Bagel.forward_cache_update_text, bagel.py:844-874."""
+    emb = p["language_model.model.embed_tokens.weight"][packed_text_ids]
+    _, past = llm_forward_inference(p, dims, emb, text_token_lens, packed_text_position_ids,
+                                    packed_text_indexes, past, key_values_lens, packed_key_value_indexes,
+                                    update_past_key_values=True, is_causal=True, mode="und")
+    return past
+
+
+def prepare_vae_latent(dims, curr_kvlens, curr_rope, image_sizes, new_token_ids):
+    """Bagel.prepare_vae_latent, bagel.py:1145-1201 (one CPU randn per image, in order)."""
+    text_ids, text_idx, vae_pos, vae_idx, noises = [], [], [], [], []
+    pos_ids, seqlens, idx, kvidx = [], [], [], []
+    qc = c = 0
+    for (H, W), kvlen, rope in zip(image_sizes, curr_kvlens, curr_rope):
+        kvidx.extend(range(c, c + kvlen))
+        c += kvlen
+        text_ids.append(new_token_ids["start_of_image"])
+        text_idx.append(qc)
+        idx.append(c)
+        c += 1
+        qc += 1
+        vae_pos.append(flattened_position_ids_extrapolate(H, W, dims.latent_downsample, dims.max_latent_size))
+        h, w = H // dims.latent_downsample, W // dims.latent_downsample
+        n = h * w
+        noises.append(torch.randn(n, dims.patch_latent_dim))
+        vae_idx.extend(range(qc, qc + n))
+        idx.extend(range(c, c + n))
+        c += n
+        qc += n
+        text_ids.append(new_token_ids["end_of_image"])
+        text_idx.append(qc)
+        idx.append(c)
+        c += 1
+        qc += 1
+        pos_ids.extend([rope] * (n + 2))
+        seqlens.append(n + 2)
+    return {
+        "packed_text_ids": torch.tensor(text_ids, dtype=torch.long),
+        "packed_text_indexes": torch.tensor(text_idx, dtype=torch.long),
+        "packed_init_noises": torch.cat(noises, dim=0),
+        "packed_vae_position_ids": torch.cat(vae_pos, dim=0),
+        "packed_vae_token_indexes": torch.tensor(vae_idx, dtype=torch.long),
+        "packed_seqlens": torch.tensor(seqlens, dtype=torch.int),
+        "packed_position_ids": torch.tensor(pos_ids, dtype=torch.long),
+        "key_values_lens": torch.tensor(curr_kvlens, dtype=torch.int),
+        "packed_indexes": torch.tensor(idx, dtype=torch.long),
+        "packed_key_value_indexes": torch.tensor(kvidx, dtype=torch.long),
+    }
+
+
+def prepare_vae_latent_cfg(dims, curr_kvlens, curr_rope, image_sizes):
+    """Bagel.prepare_vae_latent_cfg, bagel.py:1203-1234."""
+    pos_ids, idx, kvidx = [], [], []
+    c = 0
+    for (H, W), kvlen, rope in zip(image_sizes, curr_kvlens, curr_rope):
+        kvidx.extend(range(c, c + kvlen))
+        c += kvlen
+        n = (H // dims.latent_downsample) * (W // dims.latent_downsample)
+        idx.extend(range(c, c + n + 2))
+        c += n + 2
+        pos_ids.extend([rope] * (n + 2))
+    return {
+        "cfg_packed_position_ids": torch.tensor(pos_ids, dtype=torch.long),
+        "cfg_key_values_lens": torch.tensor(curr_kvlens, dtype=torch.int),
+        "cfg_packed_query_indexes": torch.tensor(idx, dtype=torch.long),
+        "cfg_packed_key_value_indexes": torch.tensor(kvidx, dtype=torch.long),
+    }
+
+
+# ----------------------------------------------------------------------------
+# flow step and sampler
+# ----------------------------------------------------------------------------
+def cfg_combine(v_t, cfg_text_v_t, cfg_img_v_t, cfg_text_scale, cfg_img_scale, cfg_renorm_min, cfg_renorm_type):
+    """CFG combine + renorm, bagel.py:1466-1500."""
+    if cfg_text_scale > 1.0:
+        if cfg_renorm_type == "text_channel":
+            v_text_ = cfg_text_v_t + cfg_text_scale * (v_t - cfg_text_v_t)
+            n0 = torch.norm(v_t, dim=-1, keepdim=True)
+            n1 = torch.norm(v_text_, dim=-1, keepdim=True)
+            scale = (n0 / (n1 + 1e-8)).clamp(min=cfg_renorm_min, max=1.0)
+            v_text = v_text_ * scale
+            if cfg_img_scale > 1.0:
+                v_t = cfg_img_v_t + cfg_img_scale * (v_text - cfg_img_v_t)
+            else:
+                v_t = v_text
+        else:
+            v_text_ = cfg_text_v_t + cfg_text_scale * (v_t - cfg_text_v_t)
+            if cfg_img_scale > 1.0:
+                v_ = cfg_img_v_t + cfg_img_scale * (v_text_ - cfg_img_v_t)
+            else:
+                v_ = v_text_
+            if cfg_renorm_type == "global":
+                n0 = torch.norm(v_t)
+                n1 = torch.norm(v_)
+            elif cfg_renorm_type == "channel":
+                n0 = torch.norm(v_t, dim=-1, keepdim=True)
+                n1 = torch.norm(v_, dim=-1, keepdim=True)
+            else:
+                raise NotImplementedError(f"{cfg_renorm_type} is not suppoprted")
+            scale = (n0 / (n1 + 1e-8)).clamp(min=cfg_renorm_min, max=1.0)
+            v_t = v_ * scale
+    return v_t
+
+
+def forward_flow(p, dims, x_t, timestep, packed_vae_token_indexes, packed_vae_position_ids, packed_text_ids,
+                 packed_text_indexes, packed_indexes, packed_position_ids, packed_seqlens, key_values_lens,
+                 past_key_values, packed_key_value_indexes, cfg_renorm_min=0.0, cfg_renorm_type="global",
+                 cfg_text_scale=1.0, cfg_text_packed_position_ids=None, cfg_text_packed_query_indexes=None,
+                 cfg_text_key_values_lens=None, cfg_text_past_key_values=None,
+                 cfg_text_packed_key_value_indexes=None,
+                 cfg_img_scale=1.0, cfg_img_packed_position_ids=None, cfg_img_packed_query_indexes=None,
+                 cfg_img_key_values_lens=None, cfg_img_past_key_values=None,
+                 cfg_img_packed_key_value_indexes=None, return_branches=False):
+    """Bagel._forward_flow, bagel.py:1350-1500."""
+    emb = p["language_model.model.embed_tokens.weight"][packed_text_ids]
+    seq = emb.new_zeros((int(sum(packed_seqlens)), dims.hidden_size))
+    seq[packed_text_indexes] = emb
+    assert timestep.unique().shape[0] == 1
+    pos = p["latent_pos_embed.pos_embed"][packed_vae_position_ids]
+    temb = time_embedder(p, timestep, dims.timestep_freq_dim)
+    h = linear(x_t, p["vae2llm.weight"], p["vae2llm.bias"]) + temb + pos
+    seq[packed_vae_token_indexes] = h.to(seq.dtype)
+
+    def branch(pos_ids, q_idx, past, kvl, kv_idx):
+        out, _ = llm_forward_inference(p, dims, seq, packed_seqlens, pos_ids, q_idx, past, kvl, kv_idx,
+                                       update_past_key_values=False, is_causal=False, mode="gen",
+                                       packed_vae_token_indexes=packed_vae_token_indexes,
+                                       packed_text_indexes=packed_text_indexes)
+        return linear(out, p["llm2vae.weight"], p["llm2vae.bias"])[packed_vae_token_indexes]
+
+    v_t = branch(packed_position_ids, packed_indexes, past_key_values, key_values_lens, packed_key_value_indexes)
+    v_text = v_img = None
+    if cfg_text_scale > 1.0:
+        v_text = branch(cfg_text_packed_position_ids, cfg_text_packed_query_indexes, cfg_text_past_key_values,
+                        cfg_text_key_values_lens, cfg_text_packed_key_value_indexes)
+    if cfg_img_scale > 1.0:
+        v_img = branch(cfg_img_packed_position_ids, cfg_img_packed_query_indexes, cfg_img_past_key_values,
+                       cfg_img_key_values_lens, cfg_img_packed_key_value_indexes)
+    out = cfg_combine(v_t, v_text, v_img, cfg_text_scale, cfg_img_scale, cfg_renorm_min, cfg_renorm_type)
+    if return_branches:
+        return out, (v_t, v_text, v_img)
+    return out
+
+
+def flow_timesteps(num_timesteps: int, timestep_shift: float):
+    """bagel.py:1286-1289."""
+    t = torch.linspace(1, 0, num_timesteps)
+    t = timestep_shift * t / (1 + (timestep_shift - 1) * t)
+    return t[:-1], t[:-1] - t[1:]
+
+
+def generate_image(p, dims, packed_text_ids, packed_text_indexes, packed_init_noises, packed_vae_position_ids,
+                   packed_vae_token_indexes, packed_seqlens, packed_position_ids, packed_indexes,
+                   past_key_values, key_values_lens, packed_key_value_indexes, num_timesteps=24,
+                   timestep_shift=1.0, cfg_renorm_min=0.0, cfg_renorm_type="global", cfg_interval=(0, 1),
+                   cfg_text_scale=1.0, cfg_img_scale=1.0, trace: Optional[list] = None, max_steps=None,
+                   **cfg_kwargs):
+    """Bagel.generate_image, bagel.py:1237-1347 (TaylorSeer off).  ``trace`` collects per-step tensors."""
+    x_t = packed_init_noises
+    timesteps, dts = flow_timesteps(num_timesteps, timestep_shift)
+    for i, t in enumerate(timesteps):
+        if max_steps is not None and i >= max_steps:
+            break
+        timestep = torch.tensor([t] * x_t.shape[0])
+        if t > cfg_interval[0] and t <= cfg_interval[1]:
+            ts_, is_ = cfg_text_scale, cfg_img_scale
+        else:
+            ts_, is_ = 1.0, 1.0
+        v_t, br = forward_flow(p, dims, x_t, timestep, packed_vae_token_indexes, packed_vae_position_ids,
+                               packed_text_ids, packed_text_indexes, packed_indexes, packed_position_ids,
+                               packed_seqlens, key_values_lens, past_key_values, packed_key_value_indexes,
+                               cfg_renorm_min=cfg_renorm_min, cfg_renorm_type=cfg_renorm_type,
+                               cfg_text_scale=ts_, cfg_img_scale=is_, return_branches=True, **cfg_kwargs)
+        if trace is not None:
+            trace.append({"x_t": x_t, "v_t": v_t, "v_cond": br[0], "v_text": br[1], "v_img": br[2]})
+        x_t = x_t - v_t.to(x_t.device) * dts[i]
+    return x_t.split((packed_seqlens - 2).tolist())
+
+
+# ----------------------------------------------------------------------------
+# FLUX VAE decoder
+# ----------------------------------------------------------------------------
+def _conv(x, p, name, padding, bf16):
+    w, b = p[name + ".weight"], p[name + ".bias"]
+    if bf16:
+        return F.conv2d(x.to(BF16), w.to(BF16), b.to(BF16), padding=padding)
+    return F.conv2d(x, w, b, padding=padding)
+
+
+def _gn_swish(x, p, name, swish=True):
+    """GroupNorm(32, eps 1e-6) evaluated in fp32 (autocast keeps normalisation in fp32), then x*sigmoid(x)."""
+    h = F.group_norm(x.float(), 32, p[name + ".weight"].float(), p[name + ".bias"].float(), eps=1e-6)
+    return h * torch.sigmoid(h) if swish else h
+
+
+def _resblock(x, p, name, bf16):
+    """ResnetBlock.forward, modeling/autoencoder.py:82-95."""
+    h = _conv(_gn_swish(x, p, name + ".norm1"), p, name + ".conv1", 1, bf16)
+    h = _conv(_gn_swish(h, p, name + ".norm2"), p, name + ".conv2", 1, bf16)
+    if (name + ".nin_shortcut.weight") in p:
+        x = _conv(x, p, name + ".nin_shortcut", 0, bf16)
+    return x + h
+
+
+def _attnblock(x, p, name, bf16):
+    """AttnBlock.forward, autoencoder.py:50-65: single-head attention over h*w tokens, head dim = channels."""
+    h = _gn_swish(x, p, name + ".norm", swish=False)
+    q = _conv(h, p, name + ".q", 0, bf16)
+    k = _conv(h, p, name + ".k", 0, bf16)
+    v = _conv(h, p, name + ".v", 0, bf16)
+    b, c, hh, ww = q.shape
+    q, k, v = (t.reshape(b, 1, c, hh * ww).transpose(2, 3).contiguous() for t in (q, k, v))
+    o = F.scaled_dot_product_attention(q, k, v)
+    o = o.transpose(2, 3).reshape(b, c, hh, ww)
+    return x + _conv(o, p, name + ".proj_out", 0, bf16)
+
+
+def vae_decode(p, vdims, z: torch.Tensor, bf16: bool = True) -> torch.Tensor:
+    """AutoEncoder.decode + Decoder.forward, autoencoder.py:250-272,320-322.
+
+    ``bf16`` = convolutions and attention on bf16 operands (what bf16 autocast does to the fp32 VAE).
+    """
+    z = z / vdims.scale_factor + vdims.shift_factor
+    h = _conv(z, p, "decoder.conv_in", 1, bf16)
+    h = _resblock(h, p, "decoder.mid.block_1", bf16)
+    h = _attnblock(h, p, "decoder.mid.attn_1", bf16)
+    h = _resblock(h, p, "decoder.mid.block_2", bf16)
+    nres = len(vdims.ch_mult)
+    for lvl in reversed(range(nres)):
+        for b in range(vdims.num_res_blocks + 1):
+            h = _resblock(h, p, f"decoder.up.{lvl}.block.{b}", bf16)
+        if lvl != 0:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = _conv(h, p, f"decoder.up.{lvl}.upsample.conv", 1, bf16)
+    h = _gn_swish(h, p, "decoder.norm_out")
+    return _conv(h, p, "decoder.conv_out", 1, bf16)
+
+
+def unpatchify_latent(dims, latent: torch.Tensor, image_shape) -> torch.Tensor:
+    """InterleaveInferencer.decode_image, inferencer.py:201-207."""
+    H, W = image_shape
+    h, w = H // dims.latent_downsample, W // dims.latent_downsample
+    p_, c = dims.latent_patch_size, dims.latent_channel
+    latent = latent.reshape(1, h, w, p_, p_, c)
+    latent = torch.einsum("nhwpqc->nchpwq", latent)
+    return latent.reshape(1, c, h * p_, w * p_)
+
+
+def to_uint8_image(image: torch.Tensor) -> torch.Tensor:
+    """inferencer.py:209-210."""
+    return ((image * 0.5 + 0.5).clamp(0, 1)[0].permute(1, 2, 0) * 255).to(torch.uint8)

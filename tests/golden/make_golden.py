@@ -1,0 +1,166 @@
+"""Capture golden vectors from the reference's own PyTorch path (authoring container only).
+
+    python tests/golden/make_golden.py [scenario ...]      # default: all LLM scenarios + VAE
+
+For every scenario of tests/scenarios.py this imports the reference from
+/root/reference (see ref_harness.py for the shims), loads the repo's seeded
+weights into the reference ``Bagel``, builds the three CFG contexts with the
+reference's ``prepare_prompts`` / ``forward_cache_update_text``, runs the
+reference's ``generate_image`` and records, per Euler step: the input ``x_t``,
+each branch's velocity before CFG, and the combined velocity; plus the final
+latent.  VAE scenarios record ``AutoEncoder.decode`` outputs.  The files written
+here (tests/golden/*.safetensors) are the only thing that travels to the GPU box.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import torch
+from safetensors.torch import save_file
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+import ref_harness as rh  # noqa: E402
+from scenarios import SCENARIOS, NEW_TOKEN_IDS  # noqa: E402
+from bagel_amd.config import VAEDims  # noqa: E402
+from bagel_amd.weights import make_llm_state_dict, make_vae_decoder_state_dict  # noqa: E402
+
+
+def build_context(model, NaiveCache, prompts, n_samples, tok):
+    """Prefill one CFG context the way InterleaveInferencer.update_context_text does (inferencer.py:57-76)."""
+    past = NaiveCache(model.config.llm_config.num_hidden_layers)
+    kvlens, ropes = [0] * n_samples, [0] * n_samples
+    if prompts is not None:
+        gi, kvlens, ropes = model.prepare_prompts(kvlens, ropes, [" ".join(map(str, p)) for p in prompts],
+                                                  tok, NEW_TOKEN_IDS)
+        past = model.forward_cache_update_text(past, **gi)
+    return past, kvlens, ropes
+
+
+def run_llm_scenario(sc):
+    t0 = time.time()
+    sd = make_llm_state_dict(sc.dims, seed=sc.weight_seed)
+    model = rh.build_reference_model(sc.dims, sd)
+    from modeling.bagel.qwen2_navit import NaiveCache
+    tok = rh.StandInTokenizer()
+    n = len(sc.images)
+    out = {}
+    with torch.no_grad(), rh.autocast():
+        ctx = {w: build_context(model, NaiveCache, sc.prompts(w), n, tok) for w in ("cond", "text", "img")}
+        torch.manual_seed(sc.noise_seed)
+        gi = model.prepare_vae_latent(ctx["cond"][1], ctx["cond"][2], sc.images, NEW_TOKEN_IDS)
+        gt = model.prepare_vae_latent_cfg(ctx["text"][1], ctx["text"][2], sc.images)
+        gm = model.prepare_vae_latent_cfg(ctx["img"][1], ctx["img"][2], sc.images)
+        out["init_noise"] = gi["packed_init_noises"].clone()
+
+        steps = []
+        branch_v = []
+        orig_flow = model._forward_flow
+        vae_idx = gi["packed_vae_token_indexes"]
+        hook = model.llm2vae.register_forward_hook(lambda m, i, o: branch_v.append(o[vae_idx].clone()))
+
+        class Stop(Exception):
+            pass
+
+        def flow(**kw):
+            if sc.max_steps is not None and len(steps) >= sc.max_steps:
+                raise Stop()
+            branch_v.clear()
+            v = orig_flow(**kw)
+            rec = {"x_t": kw["x_t"].clone(), "v_t": v.clone(), "v_cond": branch_v[0]}
+            k = 1
+            if kw["cfg_text_scale"] > 1.0:
+                rec["v_text"] = branch_v[k]
+                k += 1
+            if kw["cfg_img_scale"] > 1.0:
+                rec["v_img"] = branch_v[k]
+            steps.append(rec)
+            print(f"  [{sc.name}] step {len(steps)} done at {time.time() - t0:.1f}s", flush=True)
+            return v
+
+        model._forward_flow = flow
+        try:
+            latents = model.generate_image(
+                past_key_values=ctx["cond"][0], num_timesteps=sc.num_timesteps, timestep_shift=sc.timestep_shift,
+                cfg_renorm_min=sc.cfg_renorm_min, cfg_renorm_type=sc.cfg_renorm_type,
+                cfg_interval=list(sc.cfg_interval), cfg_text_scale=sc.cfg_text_scale,
+                cfg_text_past_key_values=ctx["text"][0],
+                cfg_text_packed_position_ids=gt["cfg_packed_position_ids"],
+                cfg_text_packed_query_indexes=gt["cfg_packed_query_indexes"],
+                cfg_text_key_values_lens=gt["cfg_key_values_lens"],
+                cfg_text_packed_key_value_indexes=gt["cfg_packed_key_value_indexes"],
+                cfg_img_scale=sc.cfg_img_scale, cfg_img_past_key_values=ctx["img"][0],
+                cfg_img_packed_position_ids=gm["cfg_packed_position_ids"],
+                cfg_img_packed_query_indexes=gm["cfg_packed_query_indexes"],
+                cfg_img_key_values_lens=gm["cfg_key_values_lens"],
+                cfg_img_packed_key_value_indexes=gm["cfg_packed_key_value_indexes"], **gi)
+            out["final_latent"] = torch.cat(list(latents), dim=0).clone()
+        except Stop:
+            pass
+        hook.remove()
+        for i, rec in enumerate(steps):
+            for k, v in rec.items():
+                out[f"step{i}.{k}"] = v
+        # context KV of the cond branch, layer 0 and last layer (pins the prefill path)
+        pk = ctx["cond"][0]
+        if pk.key_cache[0] is not None:
+            last = sc.dims.num_layers - 1
+            out["cond_ctx.k0"] = pk.key_cache[0].clone()
+            out["cond_ctx.v0"] = pk.value_cache[0].clone()
+            out["cond_ctx.k_last"] = pk.key_cache[last].clone()
+            out["cond_ctx.v_last"] = pk.value_cache[last].clone()
+    # Rounding-noise floor of the scenario: distance between the reference's bf16 result and the
+    # exact-arithmetic (fp32, no rounding points) evaluation of the same step by the CPU checker.
+    from helpers import OracleRun
+    exact = OracleRun(sc, exact=True)
+    noise = {}
+    for i, rec in enumerate(steps):
+        vt, (c, x, m) = exact.step(i, rec["x_t"])
+        for key, t in (("v_cond", c), ("v_text", x), ("v_img", m), ("v_t", vt)):
+            if key in rec:
+                a, b = rec[key].float().flatten(), t.float().flatten()
+                d = (a - b).abs()
+                noise[f"step{i}.{key}"] = [float(d.max()), float(d.mean()),
+                                           float(torch.dot(a, b) / (a.norm() * b.norm()))]
+    print(f"  [{sc.name}] reference-vs-exact noise floor: max {max(v[0] for v in noise.values()):.4f} "
+          f"mean {max(v[1] for v in noise.values()):.5f}")
+    meta = {"scenario": sc.name, "n_steps": str(len(steps)), "torch": torch.__version__,
+            "noise_floor": json.dumps(noise),
+            "source": "reference Bagel.generate_image on CPU, bf16 weights + bf16 autocast, SDPA stand-in for flash_attn"}
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, f"{sc.name}.safetensors"), metadata=meta)
+    print(f"[{sc.name}] wrote {len(out)} tensors in {time.time() - t0:.1f}s")
+
+
+VAE_CASES = {"vae_128": (16, 16), "vae_256": (32, 32), "vae_512x384": (64, 48)}
+
+
+def run_vae(name, latent_hw):
+    t0 = time.time()
+    vd = VAEDims()
+    sd = make_vae_decoder_state_dict(vd, seed=0)
+    ae = rh.build_reference_vae(vd, sd)
+    g = torch.Generator().manual_seed(7)
+    z = torch.randn(1, vd.z_channels, *latent_hw, generator=g)
+    with torch.no_grad():
+        img32 = ae.decode(z)
+        with rh.autocast():
+            img16 = ae.decode(z)
+    save_file({"z": z, "image_fp32": img32.float().contiguous(), "image_autocast": img16.float().contiguous()},
+              os.path.join(HERE, f"{name}.safetensors"),
+              metadata={"source": "reference AutoEncoder.decode on CPU, fp32 and under bf16 autocast"})
+    print(f"[{name}] wrote in {time.time() - t0:.1f}s; |fp32-autocast|max={float((img32 - img16.float()).abs().max()):.4f}")
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or (list(SCENARIOS) + list(VAE_CASES))
+    for nme in names:
+        if nme in SCENARIOS:
+            run_llm_scenario(SCENARIOS[nme])
+        else:
+            run_vae(nme, VAE_CASES[nme])
