@@ -1,0 +1,185 @@
+"""Build and load libbagel_hip.so (the C-ABI of include/bagel_hip.h) and wrap it for torch tensors.
+
+There is no fallback: if the library is missing or an entry point fails, a RuntimeError is raised.
+torch is used only to own device memory and to name the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import subprocess
+from typing import Optional
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "libbagel_hip.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "bagel_hip.h")
+SOURCES = ["capi.hip", "gemm.hip", "skinny.hip", "attention.hip", "elementwise.hip", "vae.hip"]
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into bagel_amd/libbagel_hip.so (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, "common.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for s in srcs:
+        o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
+        objs.append(o)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", s, "-o", o]
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + out.decode())
+        if verbose and out:
+            print(out.decode())
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed: " + r.stdout.decode())
+    return LIB_PATH
+
+
+def declared_symbols() -> list:
+    """Entry points declared in include/bagel_hip.h."""
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bagel_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the HIP extension is the only compute path; there is no fallback)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.bagel_last_error.restype = ctypes.c_char_p
+        for name in ("bagel_skinny_gemm_workspace_bytes", "bagel_cfg_workspace_bytes", "bagel_vae_workspace_bytes"):
+            if hasattr(_lib, name):
+                getattr(_lib, name).restype = ctypes.c_long
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().bagel_last_error().decode()
+        if "is not supported" in msg and "cfg_renorm_type" in msg:
+            raise NotImplementedError(msg)
+        raise RuntimeError(f"{what} failed ({rc}): {msg}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return ctypes.c_void_p(0)
+    assert t.is_cuda, "device tensor expected"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+L = ctypes.c_long
+I = ctypes.c_int
+F = ctypes.c_float
+
+EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2
+SK_BIAS, SK_RESIDUAL, SK_SWIGLU, SK_BIAS_SILU = 0, 1, 2, 3
+RENORM = {"global": 0, "channel": 1, "text_channel": 2}
+
+
+def gemm(A, W, C, bias=None, residual=None, epilogue=EPI_BIAS, M=None):
+    """C[M,N] = epilogue(A[M,K] @ W[N,K]^T) (bf16 2-D tensors, rows may be strided)."""
+    M = A.shape[0] if M is None else M
+    N, K = W.shape
+    assert A.dtype == W.dtype == C.dtype == torch.bfloat16 and A.shape[1] == K
+    assert A.stride(1) == 1 and W.stride(1) == 1 and C.stride(1) == 1
+    _check(lib().bagel_gemm_bf16(_p(A), L(A.stride(0)), _p(W), L(W.stride(0)), _p(C), L(C.stride(0)), I(M), I(N), I(K),
+                                 _p(bias), _p(residual), L(residual.stride(0) if residual is not None else 0),
+                                 I(epilogue), _stream()), "bagel_gemm_bf16")
+    return C
+
+
+def skinny_workspace_bytes(M, N):
+    return lib().bagel_skinny_gemm_workspace_bytes(I(M), I(N))
+
+
+def skinny_gemm(X, W, C, workspace, bias=None, residual=None, epilogue=SK_BIAS):
+    M, K = X.shape
+    N = W.shape[0]
+    assert X.dtype == W.dtype == C.dtype == torch.bfloat16 and W.shape[1] == K
+    _check(lib().bagel_skinny_gemm_bf16(_p(X), L(X.stride(0)), _p(W), L(W.stride(0)), _p(C), L(C.stride(0)), I(M), I(N),
+                                        I(K), _p(bias), _p(residual),
+                                        L(residual.stride(0) if residual is not None else 0), I(epilogue),
+                                        _p(workspace), L(workspace.numel() * workspace.element_size()), _stream()),
+           "bagel_skinny_gemm_bf16")
+    return C
+
+
+def rmsnorm(x, out, w_first, w_second, split_row, eps, rows=None):
+    rows = x.shape[0] if rows is None else rows
+    _check(lib().bagel_rmsnorm_bf16(_p(x), L(x.stride(0)), _p(out), L(out.stride(0)), I(rows), I(x.shape[1]),
+                                    _p(w_first), _p(w_second), I(split_row), F(eps), _stream()), "bagel_rmsnorm_bf16")
+    return out
+
+
+def qk_norm_rope_kv(qkv, M, Hq, Hkv, D, qn_first, qn_second, kn_first, kn_second, split_row, cos_t, sin_t, row_cs,
+                    row_slot, Q, K_ws, Vt_ws, S, eps, und_rounding=False):
+    _check(lib().bagel_qk_norm_rope_kv_bf16(_p(qkv), L(qkv.stride(0)), I(M), I(Hq), I(Hkv), I(D), _p(qn_first),
+                                            _p(qn_second), _p(kn_first), _p(kn_second), I(split_row), _p(cos_t),
+                                            _p(sin_t), _p(row_cs), _p(row_slot), _p(Q), _p(K_ws), _p(Vt_ws), L(S),
+                                            F(eps), I(1 if und_rounding else 0), _stream()),
+           "bagel_qk_norm_rope_kv_bf16")
+
+
+def varlen_attention(Q, K_ws, Vt_ws, O, tiles, n_tiles, Hq, Hkv, D, S):
+    _check(lib().bagel_varlen_attention_bf16(_p(Q), _p(K_ws), _p(Vt_ws), _p(O), _p(tiles), I(n_tiles), I(Hq), I(Hkv),
+                                             I(D), L(S), _stream()), "bagel_varlen_attention_bf16")
+    return O
+
+
+def embed_latent(lin, temb, pos_table, pos_id, src_row, X, rows):
+    _check(lib().bagel_embed_latent_bf16(_p(lin), L(lin.stride(0)), _p(temb), _p(pos_table), _p(pos_id), _p(src_row),
+                                         _p(X), L(X.stride(0)), I(rows), I(X.shape[1]), _stream()),
+           "bagel_embed_latent_bf16")
+
+
+def gather_rows(table, idx, out, rows):
+    _check(lib().bagel_gather_rows_bf16(_p(table), L(table.stride(0)), _p(idx), _p(out), L(out.stride(0)), I(rows),
+                                        I(out.shape[1]), _stream()), "bagel_gather_rows_bf16")
+
+
+def timestep_sinusoid(t, out):
+    _check(lib().bagel_timestep_sinusoid_bf16(_p(t), I(t.numel()), I(out.shape[1]), _p(out), _stream()),
+           "bagel_timestep_sinusoid_bf16")
+
+
+def cast_f32_bf16(x, out):
+    _check(lib().bagel_cast_f32_bf16(_p(x), _p(out), L(x.numel()), _stream()), "bagel_cast_f32_bf16")
+
+
+def cfg_workspace_bytes(rows, P):
+    return lib().bagel_cfg_workspace_bytes(I(rows), I(P))
+
+
+def cfg_euler_update(v_cond, v_text, v_img, cfg_text_scale, cfg_img_scale, renorm_type, renorm_min, dt, x_t, x_bf16,
+                     v_t_out, workspace):
+    if renorm_type not in RENORM:
+        raise NotImplementedError(f"{renorm_type} is not suppoprted")
+    rows, P = x_t.shape
+    _check(lib().bagel_cfg_euler_update(_p(v_cond), _p(v_text), _p(v_img), F(cfg_text_scale), F(cfg_img_scale),
+                                        I(RENORM[renorm_type]), F(renorm_min), F(dt), _p(x_t), _p(x_bf16),
+                                        _p(v_t_out), I(rows), I(P), _p(workspace),
+                                        L(workspace.numel() * workspace.element_size()), _stream()),
+           "bagel_cfg_euler_update")

@@ -1,0 +1,239 @@
+// Packed varlen GQA attention for the generation forward (gfx950).
+//
+// Replaces flash_attn_varlen_func as called from PackedAttentionMoT.forward_inference
+// (qwen2_navit.py:590-599) together with the per-layer rebuild of the merged K/V tensors
+// (qwen2_navit.py:570-585): keys/values live in a persistent workspace where each sample's context
+// and its query tokens are adjacent, so a query tile just walks one contiguous key range.
+//
+// Workspace layout per layer (bf16), S = padded total key slots, every sample's range starts at a
+// multiple of 64 slots:
+//     K  [Hkv][S][D]      row-major keys (RoPE already applied)
+//     Vt [Hkv][D][S]      values TRANSPOSED, so that a lane's MFMA operand is 8 consecutive keys
+//
+// One workgroup = 4 waves = 128 query rows of one query head; each wave owns 32 rows.  Per 64-key tile:
+//     S^T = K . Q^T        (keys on the MFMA row index, query row on the lane)
+//     online softmax       (row statistics are lane-local; halves combined with one cross-lane swap)
+//     O^T += Vt . P^T      (the S^T accumulators, rounded to bf16, ARE the B operand: no LDS round trip)
+// K rows are fed to the first product in the order key pi(i) = i with bits 2 and 3 swapped, which makes
+// the accumulator-as-operand k order of the second product the natural key order.
+// K/V tiles arrive by 16-byte LDS-DMA into two LDS buffers (one barrier per tile); the XOR swizzles are
+// applied to the DMA source address and to the fragment reads.
+// Arithmetic follows FlashAttention-2: fp32 scores and statistics, P rounded to bf16 for P.V,
+// fp32 accumulation, division by the fp32 row sum at the end.
+#include "common.h"
+
+struct AttnTile {
+  int q_row0;    // first query row (row index into Q / O)
+  int n_rows;    // valid rows in this tile (<= 128)
+  int kv_start;  // first key slot of the sample (multiple of 64)
+  int kv_len;    // number of valid keys
+};
+
+struct AttnParams {
+  const bf16* Q;   // [M][Hq][D]
+  const bf16* K;   // [Hkv][S][D]
+  const bf16* Vt;  // [Hkv][D][S]
+  bf16* O;         // [M][Hq][D]
+  const AttnTile* tiles;
+  int n_tiles, Hq, Hkv;
+  long S;
+  float scale_log2;  // log2(e) / sqrt(D)
+};
+
+constexpr int KT = 64;  // keys per tile
+
+template <int HD>
+__global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
+  static_assert(HD == 128, "head_dim 128 only");
+  constexpr int KS = HD / 16;        // k steps of the score product
+  constexpr int DB = HD / 32;        // 32-wide d blocks of the output
+  constexpr int K_BYTES = KT * HD * 2, V_BYTES = HD * KT * 2, STAGE = K_BYTES + V_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // work order: (kv head, tile, query head within the group) with each XCD taking a contiguous range,
+  // so the 7 query heads that share a kv head, and neighbouring query tiles, hit one XCD's L2
+  const int rep = p.Hq / p.Hkv;
+  const int nwg = p.n_tiles * p.Hq;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, loc = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int kvh = wg / (p.n_tiles * rep);
+  const int rem = wg - kvh * p.n_tiles * rep;
+  const int tile_idx = rem / rep;
+  const int head = kvh * rep + rem % rep;
+  const AttnTile t = p.tiles[tile_idx];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // ---- Q fragments (B operand of S^T): lane (row, h) holds Q[row][16*ks + 8h .. +8)
+  const int qrow = min(wave * 32 + l31, t.n_rows - 1);
+  const bf16* qp = p.Q + ((long)(t.q_row0 + qrow) * p.Hq + head) * HD + 8 * h;
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + 16 * ks);
+
+  // ---- staging: K tile = 64 rows x 256 B (4 rows per DMA piece), Vt tile = 128 rows x 128 B (8 rows per piece)
+  const bf16* kbase = p.K + ((long)kvh * p.S + t.kv_start) * HD;
+  const bf16* vbase = p.Vt + (long)kvh * HD * p.S + t.kv_start;
+  const bf16* k_src[4];
+  const bf16* v_src[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int piece = it * 4 + wave;
+    const int krow = piece * 4 + (lane >> 4);
+    k_src[it] = kbase + (long)krow * HD + (((lane & 15) ^ (krow & 15)) * 8);
+    const int vrow = piece * 8 + (lane >> 3);
+    v_src[it] = vbase + (long)vrow * p.S + (((lane & 7) ^ ((vrow >> 1) & 7)) * 8);
+  }
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(k_src[it] + (long)kt * KT * HD),
+                                       LDS_PTR(base + (it * 4 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(v_src[it] + kt * KT),
+                                       LDS_PTR(base + K_BYTES + (it * 4 + wave) * 1024), 16, 0, 0);
+  };
+
+  // ---- fragment read offsets
+  // K: A-operand row i of a 32-key block is key pi(i) (bits 2,3 swapped)
+  const int pi = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+  int k_off[2];  // per 32-key block; chunk XOR depends on ks
+  k_off[0] = pi * (HD * 2);
+  k_off[1] = (32 + pi) * (HD * 2);
+  const int k_sw = pi & 15;  // (row & 15) is the same for both blocks
+  // Vt: row d = db*32 + l31; swizzle ((row >> 1) & 7) is the same for every db (32 | row offset)
+  const int v_row_off = l31 * (KT * 2);
+  const int v_sw = (l31 >> 1) & 7;
+
+  f32x16 o_acc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int n_kt = (t.kv_len + KT - 1) / KT;
+  stage(0, 0);
+  for (int kt = 0; kt < n_kt; ++kt) {
+    __syncthreads();
+    if (kt + 1 < n_kt) stage(kt + 1, (kt + 1) & 1);
+    const char* kb = smem + (kt & 1) * STAGE;
+    const char* vb = kb + K_BYTES;
+
+    // S^T for two 32-key blocks
+    f32x16 s[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(kb + k_off[b] + (((2 * ks + h) ^ k_sw) * 16));
+        s[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[b], 0, 0, 0);
+      }
+    }
+    // scale, mask the tail keys of the last tile
+    const int key0 = kt * KT;
+    const bool tail = key0 + KT > t.kv_len;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = s[b][r] * p.scale_log2;
+        if (tail) {
+          const int key = key0 + 32 * b + (r & 3) + 4 * ((r >> 2) & 1) + 8 * h + 16 * (r >> 3);
+          v = key < t.kv_len ? v : -INFINITY;
+        }
+        s[b][r] = v;
+      }
+    // online softmax: this lane holds 32 of the row's 64 keys, lane^32 the other 32
+    float mx = s[0][0];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[b][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[b][r] - m_new);
+        s[b][r] = e;
+        psum += e;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+
+    // O^T += Vt . P^T : 4 k steps of 16 keys
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (bf16)s[b][8 * st + j];
+        const int chunk = 2 * (2 * b + st) + h;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          const bf16x8 vf = *(const bf16x8*)(vb + d * 32 * (KT * 2) + v_row_off + ((chunk ^ v_sw) * 16));
+          o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[d], 0, 0, 0);
+        }
+      }
+  }
+
+  // ---- epilogue: lane holds query row l31, d = db*32 + (r&3) + 8*(r>>2) + 4h
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int row = wave * 32 + l31;
+  if (row < t.n_rows) {
+    bf16* op = p.O + ((long)(t.q_row0 + row) * p.Hq + head) * HD;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = (bf16)(o_acc[d][4 * g + e] * inv);
+        *(bf16x4*)(op + d * 32 + 8 * g + 4 * h) = o4;
+      }
+  }
+}
+
+extern "C" int bagel_varlen_attention_bf16(const void* Q, const void* K, const void* Vt, void* O,
+                                           const void* tiles, int n_tiles, int Hq, int Hkv, int head_dim,
+                                           long S, void* stream) {
+  BAGEL_CHECK(Q && K && Vt && O && tiles, "bagel_varlen_attention_bf16: null operand");
+  BAGEL_CHECK(head_dim == 128, "bagel_varlen_attention_bf16: head_dim %d not supported (128 only)", head_dim);
+  BAGEL_CHECK(n_tiles > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "bagel_varlen_attention_bf16: bad head counts");
+  BAGEL_CHECK(S > 0 && S % 64 == 0, "bagel_varlen_attention_bf16: S=%ld must be a positive multiple of 64", S);
+  BAGEL_CHECK(((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O | (uintptr_t)tiles) % 16 == 0,
+              "bagel_varlen_attention_bf16: misaligned operand");
+  AttnParams p;
+  p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.Vt = (const bf16*)Vt; p.O = (bf16*)O;
+  p.tiles = (const AttnTile*)tiles; p.n_tiles = n_tiles; p.Hq = Hq; p.Hkv = Hkv; p.S = S;
+  p.scale_log2 = 1.4426950408889634f / sqrtf((float)head_dim);
+  const size_t lds = 2 * (KT * 128 * 2 + 128 * KT * 2);
+  auto kern = attention_kernel<128>;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    configured = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(n_tiles * Hq), dim3(256), lds, (hipStream_t)stream, p);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,46 @@
+// Shared device helpers for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// round-to-nearest-even f32 -> bf16 -> f32: the value a bf16 store followed by a load would give
+__device__ __forceinline__ float round_bf16(float x) { return (float)(bf16)x; }
+
+__device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Host-side error reporting shared by every entry point (see capi.hip).
+void bagel_set_error(const char* fmt, ...);
+
+#define BAGEL_CHECK(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      bagel_set_error(__VA_ARGS__);       \
+      return 1;                           \
+    }                                     \
+  } while (0)
+
+#define BAGEL_LAUNCH_CHECK()                                               \
+  do {                                                                     \
+    hipError_t e_ = hipGetLastError();                                     \
+    if (e_ != hipSuccess) {                                                \
+      bagel_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,       \
+                      hipGetErrorString(e_));                              \
+      return 2;                                                            \
+    }                                                                      \
+  } while (0)

@@ -1,0 +1,474 @@
+// HBM-bound kernels of the generation forward (gfx950): RMSNorm with per-modality weights, per-head
+// q/k RMSNorm + RoPE + KV-workspace scatter, latent embedding, timestep sinusoid, CFG combine + renorm +
+// Euler update.  All loads/stores of bf16 rows are 16 bytes per lane.  Rounding points follow the
+// reference's bf16 graph; each kernel names the lines it restates.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm over rows of [rows, H]; rows < split use w_first, the others w_second.
+// Qwen2RMSNorm.forward (modeling_qwen2.py:54-59): fp32 statistics, normalised value rounded to bf16,
+// then multiplied by the bf16 weight and rounded again.  Per-modality weights:
+// Qwen2MoTDecoderLayer.forward_inference (qwen2_navit.py:798-800, 826-829), final norm (:1102-1104).
+// One wave per row; the second pass re-reads the row from cache.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16* __restrict__ x, long ldx, bf16* __restrict__ out,
+                                                      long ldo, int rows, int H, const bf16* __restrict__ w_first,
+                                                      const bf16* __restrict__ w_second, int split, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const bf16* xr = x + (long)row * ldx;
+  const bf16* w = row < split ? w_first : w_second;
+  float ss = 0.f;
+  for (int c = lane * 8; c < H; c += 512) {
+    const bf16x8 v = *(const bf16x8*)(xr + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += (float)v[j] * (float)v[j];
+  }
+  ss = wave_sum(ss);
+  const float rs = rsqrtf(ss / (float)H + eps);
+  bf16* orow = out + (long)row * ldo;
+  for (int c = lane * 8; c < H; c += 512) {
+    const bf16x8 v = *(const bf16x8*)(xr + c);
+    const bf16x8 wv = *(const bf16x8*)(w + c);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)wv[j] * round_bf16((float)v[j] * rs));
+    *(bf16x8*)(orow + c) = o;
+  }
+}
+
+extern "C" int bagel_rmsnorm_bf16(const void* x, long ldx, void* out, long ldo, int rows, int H, const void* w_first,
+                                  const void* w_second, int split_row, float eps, void* stream) {
+  BAGEL_CHECK(x && out && w_first, "bagel_rmsnorm_bf16: null operand");
+  BAGEL_CHECK(rows > 0 && H > 0 && H % 8 == 0, "bagel_rmsnorm_bf16: bad shape rows=%d H=%d", rows, H);
+  BAGEL_CHECK(ldx % 8 == 0 && ldo % 8 == 0 && ldx >= H && ldo >= H, "bagel_rmsnorm_bf16: bad leading dims");
+  BAGEL_CHECK(split_row >= rows || w_second, "bagel_rmsnorm_bf16: rows past split_row need w_second");
+  BAGEL_CHECK(((uintptr_t)x | (uintptr_t)out | (uintptr_t)w_first | (uintptr_t)w_second) % 16 == 0,
+              "bagel_rmsnorm_bf16: misaligned operand");
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
+                     (bf16*)out, ldo, rows, H, (const bf16*)w_first, (const bf16*)w_second, split_row, eps);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-head RMSNorm of q and k, RoPE, and scatter into the attention operands.
+// PackedAttentionMoT.forward_inference (qwen2_navit.py:549-568, gen mode): q/k are up-cast to fp32,
+// normalised per head with the modality's weight (no intermediate rounding), rotated with the bf16
+// cos/sin of the token's position (rotate_half form, modeling_qwen2.py:154-186) and rounded to bf16 once.
+// With und_rounding != 0 the und-mode graph is followed instead (:526-530): the norm output and every
+// RoPE product are rounded to bf16.
+// q goes to Q[row][head][D]; k goes straight to its key slot of the KV workspace K[kvh][slot][D], which
+// removes the per-layer rebuild of the merged key tensor (qwen2_navit.py:574-580).
+// D/8 lanes per (row, head); lane j holds elements 8j..8j+7, its rotate_half partner is lane j ^ (D/16).
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16* __restrict__ qkv, long ld, int M, int Hq,
+                                                           int Hkv, const bf16* __restrict__ qw_first,
+                                                           const bf16* __restrict__ qw_second,
+                                                           const bf16* __restrict__ kw_first,
+                                                           const bf16* __restrict__ kw_second, int split,
+                                                           const bf16* __restrict__ cos_t,
+                                                           const bf16* __restrict__ sin_t,
+                                                           const int* __restrict__ row_cs,
+                                                           const int* __restrict__ row_slot, bf16* __restrict__ Q,
+                                                           bf16* __restrict__ Kws, long S, float eps,
+                                                           int und_rounding) {
+  constexpr int LPH = D / 8;
+  const int NH = Hq + Hkv;
+  const long item = ((long)blockIdx.x * 256 + threadIdx.x) / LPH;
+  if (item >= (long)M * NH) return;  // M*NH*LPH is a multiple of 64 only if ...; partial waves shuffle among live lanes only
+  const int j = threadIdx.x % LPH;
+  const int row = item / NH, head = item % NH;
+  const bool is_q = head < Hq;
+  const bf16* src = qkv + (long)row * ld + (long)head * D + 8 * j;  // q heads then k heads are contiguous
+  const bf16x8 v = *(const bf16x8*)src;
+  float x[8];
+  float ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    x[e] = (float)v[e];
+    ss += x[e] * x[e];
+  }
+#pragma unroll
+  for (int o = LPH / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, LPH);
+  const float rs = rsqrtf(ss / (float)D + eps);
+  const bf16* w = is_q ? (row < split ? qw_first : qw_second) : (row < split ? kw_first : kw_second);
+  const bf16x8 wv = *(const bf16x8*)(w + 8 * j);
+  const long cs = (long)row_cs[row] * D + 8 * j;
+  const bf16x8 cv = *(const bf16x8*)(cos_t + cs);
+  const bf16x8 sv = *(const bf16x8*)(sin_t + cs);
+  float y[8], yr[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float n = x[e] * rs;
+    y[e] = und_rounding ? round_bf16((float)wv[e] * round_bf16(n)) : (float)wv[e] * n;
+  }
+  const float sign = j < LPH / 2 ? -1.f : 1.f;  // rotate_half: first half gets -x2, second half +x1
+#pragma unroll
+  for (int e = 0; e < 8; ++e) yr[e] = sign * __shfl_xor(y[e], LPH / 2, LPH);
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float c = (float)cv[e], s = (float)sv[e];
+    if (und_rounding)
+      o[e] = (bf16)(round_bf16(y[e] * c) + round_bf16(yr[e] * s));
+    else
+      o[e] = (bf16)(__fmul_rn(y[e], c) + __fmul_rn(yr[e], s));
+  }
+  if (is_q)
+    *(bf16x8*)(Q + ((long)row * Hq + head) * D + 8 * j) = o;
+  else
+    *(bf16x8*)(Kws + ((long)(head - Hq) * S + row_slot[row]) * D + 8 * j) = o;
+}
+
+// V rows of the fused qkv projection -> transposed value workspace Vt[kvh][d][slot] (2-byte stores,
+// consecutive lanes = consecutive token rows = consecutive slots, so a wave writes 128 contiguous bytes).
+template <int D>
+__global__ __launch_bounds__(256) void v_scatter_transposed_kernel(const bf16* __restrict__ qkv, long ld, int M,
+                                                                    int v_col0, int Hkv,
+                                                                    const int* __restrict__ row_slot,
+                                                                    bf16* __restrict__ Vt, long S) {
+  const int row = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;          // 4 waves split the Hkv*D/8 chunks
+  if (row >= M) return;
+  const long slot = row_slot[row];
+  const bf16* src = qkv + (long)row * ld + v_col0;
+  const int nchunk = Hkv * D / 8;
+  for (int c = part; c < nchunk; c += 4) {
+    const bf16x8 v = *(const bf16x8*)(src + 8 * c);
+    bf16* dst = Vt + (long)(8 * c) * S + slot;  // (kvh*D + d) * S with kvh*D + d == 8c + e
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[(long)e * S] = v[e];
+  }
+}
+
+extern "C" int bagel_qk_norm_rope_kv_bf16(const void* qkv, long ld, int M, int Hq, int Hkv, int head_dim,
+                                          const void* q_norm_first, const void* q_norm_second,
+                                          const void* k_norm_first, const void* k_norm_second, int split_row,
+                                          const void* cos_table, const void* sin_table, const void* row_cs,
+                                          const void* row_slot, void* Q, void* K_ws, void* Vt_ws, long S,
+                                          float eps, int und_rounding, void* stream) {
+  BAGEL_CHECK(qkv && q_norm_first && k_norm_first && cos_table && sin_table && row_cs && row_slot && Q && K_ws && Vt_ws,
+              "bagel_qk_norm_rope_kv_bf16: null operand");
+  BAGEL_CHECK(head_dim == 128 || head_dim == 64, "bagel_qk_norm_rope_kv_bf16: head_dim %d not supported", head_dim);
+  BAGEL_CHECK(M > 0 && Hq > 0 && Hkv > 0, "bagel_qk_norm_rope_kv_bf16: bad shape");
+  BAGEL_CHECK(ld % 8 == 0 && ld >= (long)(Hq + 2 * Hkv) * head_dim, "bagel_qk_norm_rope_kv_bf16: bad leading dim");
+  BAGEL_CHECK(split_row >= M || (q_norm_second && k_norm_second), "bagel_qk_norm_rope_kv_bf16: rows past split_row need second weights");
+  hipStream_t st = (hipStream_t)stream;
+  const int lph = head_dim / 8;
+  const long threads = (long)M * (Hq + Hkv) * lph;
+  const dim3 grid((threads + 255) / 256), block(256);
+#define ARGS (const bf16*)qkv, ld, M, Hq, Hkv, (const bf16*)q_norm_first, (const bf16*)q_norm_second,                \
+             (const bf16*)k_norm_first, (const bf16*)k_norm_second, split_row, (const bf16*)cos_table,               \
+             (const bf16*)sin_table, (const int*)row_cs, (const int*)row_slot, (bf16*)Q, (bf16*)K_ws, S, eps, und_rounding
+  if (head_dim == 128) {
+    hipLaunchKernelGGL(qk_norm_rope_kernel<128>, grid, block, 0, st, ARGS);
+    hipLaunchKernelGGL(v_scatter_transposed_kernel<128>, dim3((M + 63) / 64), block, 0, st, (const bf16*)qkv, ld, M,
+                       (Hq + Hkv) * head_dim, Hkv, (const int*)row_slot, (bf16*)Vt_ws, S);
+  } else {
+    hipLaunchKernelGGL(qk_norm_rope_kernel<64>, grid, block, 0, st, ARGS);
+    hipLaunchKernelGGL(v_scatter_transposed_kernel<64>, dim3((M + 63) / 64), block, 0, st, (const bf16*)qkv, ld, M,
+                       (Hq + Hkv) * head_dim, Hkv, (const int*)row_slot, (bf16*)Vt_ws, S);
+  }
+#undef ARGS
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Latent embedding: X[r] = bf16( bf16(lin[src[r]] + temb) + pos_table[pos_id[src[r]]] )
+// Bagel._forward_flow (bagel.py:1394-1399): vae2llm(x_t) + time_embedder(t) + latent_pos_embed, each sum
+// rounded to bf16.  ``lin`` is the vae2llm projection (bias included) of one row per latent token;
+// ``src`` lets several CFG branches of one sample share that row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_latent_kernel(const bf16* __restrict__ lin, long ldl,
+                                                           const bf16* __restrict__ temb,
+                                                           const bf16* __restrict__ pos_table,
+                                                           const int* __restrict__ pos_id,
+                                                           const int* __restrict__ src_row, bf16* __restrict__ X,
+                                                           long ldx, int rows, int H) {
+  const int cpr = H / 8;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)rows * cpr) return;
+  const int r = idx / cpr, c = (idx % cpr) * 8;
+  const int s = src_row[r];
+  const bf16x8 a = *(const bf16x8*)(lin + (long)s * ldl + c);
+  const bf16x8 t = *(const bf16x8*)(temb + c);
+  const bf16x8 pe = *(const bf16x8*)(pos_table + (long)pos_id[s] * H + c);
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16)(round_bf16((float)a[e] + (float)t[e]) + (float)pe[e]);
+  *(bf16x8*)(X + (long)r * ldx + c) = o;
+}
+
+extern "C" int bagel_embed_latent_bf16(const void* lin, long ldl, const void* temb, const void* pos_table,
+                                       const void* pos_id, const void* src_row, void* X, long ldx, int rows, int H,
+                                       void* stream) {
+  BAGEL_CHECK(lin && temb && pos_table && pos_id && src_row && X, "bagel_embed_latent_bf16: null operand");
+  BAGEL_CHECK(rows > 0 && H % 8 == 0 && ldl % 8 == 0 && ldx % 8 == 0, "bagel_embed_latent_bf16: bad shape");
+  const long n = (long)rows * (H / 8);
+  hipLaunchKernelGGL(embed_latent_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)lin,
+                     ldl, (const bf16*)temb, (const bf16*)pos_table, (const int*)pos_id, (const int*)src_row,
+                     (bf16*)X, ldx, rows, H);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[r] = table[idx[r]]   (token embedding lookup, bagel.py:1389-1391; also replays saved rows)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16* __restrict__ table, long ldt,
+                                                          const int* __restrict__ idx, bf16* __restrict__ out,
+                                                          long ldo, int rows, int H) {
+  const int cpr = H / 8;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)rows * cpr) return;
+  const int r = i / cpr, c = (i % cpr) * 8;
+  const long s = idx ? idx[r] : r;
+  *(bf16x8*)(out + (long)r * ldo + c) = *(const bf16x8*)(table + s * ldt + c);
+}
+
+extern "C" int bagel_gather_rows_bf16(const void* table, long ldt, const void* idx, void* out, long ldo, int rows,
+                                      int H, void* stream) {
+  BAGEL_CHECK(table && out, "bagel_gather_rows_bf16: null operand");
+  BAGEL_CHECK(rows > 0 && H % 8 == 0 && ldt % 8 == 0 && ldo % 8 == 0, "bagel_gather_rows_bf16: bad shape");
+  const long n = (long)rows * (H / 8);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)table,
+                     ldt, (const int*)idx, (bf16*)out, ldo, rows, H);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sinusoidal timestep features for n timesteps: out[i] = [cos(t_i f_k) | sin(t_i f_k)], f_k = exp(-ln(1e4) k / half)
+// TimestepEmbedder.timestep_embedding (modeling_utils.py:88-107), fp32 math, stored bf16 because the
+// following nn.Linear runs on bf16 operands.
+// ---------------------------------------------------------------------------------------------
+__global__ void timestep_sinusoid_kernel(const float* __restrict__ t, int n, int dim, bf16* __restrict__ out) {
+  const int i = blockIdx.x, half = dim / 2;
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+    const int k = c < half ? c : c - half;
+    const float f = expf(-9.210340371976184f * (float)k / (float)half);
+    const float a = t[i] * f;
+    out[(long)i * dim + c] = (bf16)(c < half ? cosf(a) : sinf(a));
+  }
+}
+
+extern "C" int bagel_timestep_sinusoid_bf16(const void* t, int n, int dim, void* out, void* stream) {
+  BAGEL_CHECK(t && out && n > 0 && dim > 0 && dim % 2 == 0, "bagel_timestep_sinusoid_bf16: bad arguments");
+  hipLaunchKernelGGL(timestep_sinusoid_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const float*)t, n, dim,
+                     (bf16*)out);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ out, long n) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const f32x4 v = *(const f32x4*)(x + i);
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+    *(bf16x4*)(out + i) = o;
+  } else {
+    for (long k = i; k < n; ++k) out[k] = (bf16)x[k];
+  }
+}
+
+extern "C" int bagel_cast_f32_bf16(const void* x, void* out, long n, void* stream) {
+  BAGEL_CHECK(x && out && n > 0, "bagel_cast_f32_bf16: bad arguments");
+  BAGEL_CHECK(((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 8 == 0), "bagel_cast_f32_bf16: misaligned operand");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((n / 4 + 256) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)x, (bf16*)out, n);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CFG combine + renorm + Euler step.  Bagel._forward_flow (bagel.py:1466-1500) and the update
+// x_t = x_t - v_t * dt (bagel.py:1339).  Every tensor op of the reference is a bf16 op whose result is
+// rounded to bf16 (python scalars and 0-dim fp32 tensors enter as fp32 operands); torch.norm of a bf16
+// tensor accumulates in fp32 and rounds the result.
+//
+//   renorm_type 0 = global (norm over every row of the packed batch), 1 = channel (per row),
+//               2 = text_channel (per row, after the text stage only)
+// Pass 1 (rows kernel) forms the combined velocity and per-row sums of squares; for channel/text_channel
+// it also applies the row scale.  Pass 2 (one block) turns the row sums into the global scale.
+// Pass 3 applies the global scale (if any) and the Euler update, and emits the bf16 copy of x_t that the
+// next step's vae2llm projection reads.
+// ---------------------------------------------------------------------------------------------
+enum { RENORM_GLOBAL = 0, RENORM_CHANNEL = 1, RENORM_TEXT_CHANNEL = 2 };
+
+__device__ __forceinline__ float cfg_mix(float base, float v, float scale) {
+  // base + scale * (v - base) with a bf16 rounding after each op
+  return round_bf16(base + round_bf16(scale * round_bf16(v - base)));
+}
+
+__device__ __forceinline__ float renorm_scale(float ss0, float ss1, float rmin) {
+  const float n0 = round_bf16(sqrtf(ss0)), n1 = round_bf16(sqrtf(ss1));
+  const float q = round_bf16(n0 / round_bf16(n1 + 1e-8f));
+  return round_bf16(fminf(fmaxf(q, rmin), 1.0f));
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void cfg_rows_kernel(const bf16* __restrict__ v_cond, const bf16* __restrict__ v_text,
+                                                       const bf16* __restrict__ v_img, float s_text, float s_img,
+                                                       int renorm_type, float rmin, bf16* __restrict__ v_out,
+                                                       float* __restrict__ row_ss, int rows) {
+  constexpr int LPR = P / 8;
+  const long item = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
+  if (item >= rows) return;
+  const int j = threadIdx.x % LPR;
+  const long off = item * P + 8 * j;
+  const bf16x8 c = *(const bf16x8*)(v_cond + off);
+  const bf16x8 t = *(const bf16x8*)(v_text + off);
+  bf16x8 im;
+  const bool use_img = s_img > 1.0f;
+  if (use_img) im = *(const bf16x8*)(v_img + off);
+  float vc[8], a[8];
+  float ss0 = 0.f, ss1 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    vc[e] = (float)c[e];
+    a[e] = cfg_mix((float)t[e], vc[e], s_text);  // v_t_text_
+    ss0 += vc[e] * vc[e];
+  }
+  if (renorm_type == RENORM_TEXT_CHANNEL) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss1 += a[e] * a[e];
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) {
+      ss0 += __shfl_xor(ss0, o, LPR);
+      ss1 += __shfl_xor(ss1, o, LPR);
+    }
+    const float sc = renorm_scale(ss0, ss1, rmin);
+    bf16x8 o8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = round_bf16(a[e] * sc);
+      if (use_img) v = cfg_mix((float)im[e], v, s_img);
+      o8[e] = (bf16)v;
+    }
+    *(bf16x8*)(v_out + off) = o8;
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (use_img) a[e] = cfg_mix((float)im[e], a[e], s_img);
+    ss1 += a[e] * a[e];
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) {
+    ss0 += __shfl_xor(ss0, o, LPR);
+    ss1 += __shfl_xor(ss1, o, LPR);
+  }
+  bf16x8 o8;
+  if (renorm_type == RENORM_CHANNEL) {
+    const float sc = renorm_scale(ss0, ss1, rmin);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = (bf16)(a[e] * sc);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = (bf16)a[e];
+    if (j == 0) {
+      row_ss[item] = ss0;
+      row_ss[rows + item] = ss1;
+    }
+  }
+  *(bf16x8*)(v_out + off) = o8;
+}
+
+// one block: sums the per-row sums of squares in a fixed order and writes the global scale
+__global__ __launch_bounds__(1024) void cfg_global_scale_kernel(const float* __restrict__ row_ss, int rows, float rmin,
+                                                                 float* __restrict__ scale_out) {
+  __shared__ float sh[2][16];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < rows; i += 1024) {
+    a += row_ss[i];
+    b += row_ss[rows + i];
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = a;
+    sh[1][threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int w = 0; w < 16; ++w) {
+      s0 += sh[0][w];
+      s1 += sh[1][w];
+    }
+    scale_out[0] = renorm_scale(s0, s1, rmin);
+  }
+}
+
+// x -= float(bf16(v * dt)), v optionally scaled by *scale first; writes v_t (bf16) and the bf16 copy of x
+__global__ __launch_bounds__(256) void euler_update_kernel(const bf16* __restrict__ v_in, const float* __restrict__ scale,
+                                                           float dt, float* __restrict__ x, bf16* __restrict__ x_bf16,
+                                                           bf16* __restrict__ v_out, long n) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i >= n) return;
+  const bf16x8 v = *(const bf16x8*)(v_in + i);
+  const float sc = scale ? scale[0] : 1.0f;
+  const f32x4 x0 = *(const f32x4*)(x + i), x1 = *(const f32x4*)(x + i + 4);
+  float xs[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    xs[e] = x0[e];
+    xs[e + 4] = x1[e];
+  }
+  bf16x8 vo, xb;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float ve = (float)v[e];
+    if (scale) ve = round_bf16(ve * sc);
+    vo[e] = (bf16)ve;
+    xs[e] = xs[e] - round_bf16(ve * dt);
+    xb[e] = (bf16)xs[e];
+  }
+  *(f32x4*)(x + i) = f32x4{xs[0], xs[1], xs[2], xs[3]};
+  *(f32x4*)(x + i + 4) = f32x4{xs[4], xs[5], xs[6], xs[7]};
+  *(bf16x8*)(x_bf16 + i) = xb;
+  if (v_out) *(bf16x8*)(v_out + i) = vo;
+}
+
+extern "C" long bagel_cfg_workspace_bytes(int rows, int P) { return ((long)rows * P * 2 + 2L * rows * 4 + 256 + 255) / 256 * 256; }
+
+extern "C" int bagel_cfg_euler_update(const void* v_cond, const void* v_text, const void* v_img, float cfg_text_scale,
+                                      float cfg_img_scale, int renorm_type, float renorm_min, float dt, void* x_t,
+                                      void* x_bf16, void* v_t_out, int rows, int P, void* workspace,
+                                      long workspace_bytes, void* stream) {
+  BAGEL_CHECK(v_cond && x_t && x_bf16 && workspace, "bagel_cfg_euler_update: null operand");
+  BAGEL_CHECK(rows > 0 && P == 64, "bagel_cfg_euler_update: rows=%d P=%d (P must be 64)", rows, P);
+  BAGEL_CHECK(renorm_type >= 0 && renorm_type <= 2, "bagel_cfg_euler_update: cfg_renorm_type %d is not supported", renorm_type);
+  BAGEL_CHECK(workspace_bytes >= bagel_cfg_workspace_bytes(rows, P), "bagel_cfg_euler_update: workspace too small");
+  const bool cfg = cfg_text_scale > 1.0f;  // bagel.py:1466: image CFG only ever acts together with text CFG
+  if (cfg) {
+    BAGEL_CHECK(v_text, "bagel_cfg_euler_update: cfg_text_scale > 1 needs v_text");
+    BAGEL_CHECK(!(cfg_img_scale > 1.0f) || v_img, "bagel_cfg_euler_update: cfg_img_scale > 1 needs v_img");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const long n = (long)rows * P;
+  bf16* v_pre = (bf16*)workspace;
+  float* row_ss = (float*)((char*)workspace + ((n * 2 + 255) / 256) * 256);
+  float* scale = row_ss + 2L * rows;
+  const bf16* v_final = (const bf16*)v_cond;
+  const float* scale_ptr = nullptr;
+  if (cfg) {
+    const long threads = (long)rows * (P / 8);
+    hipLaunchKernelGGL(cfg_rows_kernel<64>, dim3((threads + 255) / 256), dim3(256), 0, st, (const bf16*)v_cond,
+                       (const bf16*)v_text, (const bf16*)v_img, cfg_text_scale, cfg_img_scale, renorm_type, renorm_min,
+                       v_pre, row_ss, rows);
+    v_final = v_pre;
+    if (renorm_type == RENORM_GLOBAL) {
+      hipLaunchKernelGGL(cfg_global_scale_kernel, dim3(1), dim3(1024), 0, st, row_ss, rows, renorm_min, scale);
+      scale_ptr = scale;
+    }
+  }
+  hipLaunchKernelGGL(euler_update_kernel, dim3((n / 8 + 255) / 256), dim3(256), 0, st, v_final, scale_ptr, dt,
+                     (float*)x_t, (bf16*)x_bf16, (bf16*)v_t_out, n);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,325 @@
+"""Host side of the generation forward: fused weight layout, KV workspace, launch sequence.
+
+One ``forward_gen`` call runs every local (sample, CFG-branch) unit of a flow step as ONE packed
+sequence through the 28 MoT layers: the latent tokens of all units form one contiguous row block that
+goes through the generation expert's MFMA GEMMs, the two text tokens of every unit form a second block
+that goes through the understanding expert's weight-streaming path.  Attention is non-causal and every
+query token of a sample shares one RoPE position (bagel.py:1185), so the physical row order inside a
+sample is free; only sample membership matters, and that is carried by the attention tile table.
+
+All arithmetic happens in libbagel_hip.so; torch allocates buffers and builds small index tables.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib as K
+from .config import BagelDims
+
+BF16 = torch.bfloat16
+
+
+def _interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """[16 gate rows | 16 up rows] per 16 features: the layout BAGEL_EPI_SWIGLU expects."""
+    I, H = gate.shape
+    return torch.stack([gate.view(I // 16, 16, H), up.view(I // 16, 16, H)], dim=1).reshape(2 * I, H).contiguous()
+
+
+@dataclass
+class LayerWeights:
+    wqkv: List[torch.Tensor]      # [gen, und]  [(Hq+2Hkv)*D, H]
+    bqkv: List[torch.Tensor]
+    wo: List[torch.Tensor]        # [H, Hq*D]
+    wgu: List[torch.Tensor]       # [2I, H] interleaved
+    wd: List[torch.Tensor]        # [H, I]
+    ln_in: List[torch.Tensor]
+    ln_post: List[torch.Tensor]
+    qn: List[torch.Tensor]
+    kn: List[torch.Tensor]
+
+
+class MoTWeights:
+    """Device-resident weights in the fused layouts the kernels read.  Index 0 = generation expert
+    (``*_moe_gen`` parameters), 1 = understanding expert."""
+
+    def __init__(self, dims: BagelDims, device):
+        self.dims = dims
+        self.device = device
+        self.layers: List[LayerWeights] = []
+        self.embed_tokens = None
+        self.norm = [None, None]
+        self.t0_w = self.t0_b = self.t2_w = self.t2_b = None
+        self.v2l_w = self.v2l_b = self.l2v_w = self.l2v_b = None
+        self.pos_embed = None
+
+    @classmethod
+    def from_state_dict(cls, dims: BagelDims, sd: Dict[str, torch.Tensor], device) -> "MoTWeights":
+        """``sd`` uses the reference's parameter names (the layout of ema.safetensors)."""
+        self = cls(dims, device)
+
+        def g(name):
+            return sd[name].to(device=device, dtype=BF16)
+
+        for i in range(dims.num_layers):
+            p = f"language_model.model.layers.{i}."
+            a = p + "self_attn."
+            lw = LayerWeights([], [], [], [], [], [], [], [], [])
+            for suf in ("_moe_gen", ""):
+                lw.wqkv.append(torch.cat([g(a + f"q_proj{suf}.weight"), g(a + f"k_proj{suf}.weight"),
+                                          g(a + f"v_proj{suf}.weight")], dim=0).contiguous())
+                lw.bqkv.append(torch.cat([g(a + f"q_proj{suf}.bias"), g(a + f"k_proj{suf}.bias"),
+                                          g(a + f"v_proj{suf}.bias")], dim=0).contiguous())
+                lw.wo.append(g(a + f"o_proj{suf}.weight").contiguous())
+                lw.wgu.append(_interleave_gate_up(g(p + f"mlp{suf}.gate_proj.weight"), g(p + f"mlp{suf}.up_proj.weight")))
+                lw.wd.append(g(p + f"mlp{suf}.down_proj.weight").contiguous())
+                lw.ln_in.append(g(p + f"input_layernorm{suf}.weight"))
+                lw.ln_post.append(g(p + f"post_attention_layernorm{suf}.weight"))
+                lw.qn.append(g(a + f"q_norm{suf}.weight"))
+                lw.kn.append(g(a + f"k_norm{suf}.weight"))
+            self.layers.append(lw)
+        self.embed_tokens = g("language_model.model.embed_tokens.weight")
+        self.norm = [g("language_model.model.norm_moe_gen.weight"), g("language_model.model.norm.weight")]
+        self.t0_w, self.t0_b = g("time_embedder.mlp.0.weight"), g("time_embedder.mlp.0.bias")
+        self.t2_w, self.t2_b = g("time_embedder.mlp.2.weight"), g("time_embedder.mlp.2.bias")
+        self.v2l_w, self.v2l_b = g("vae2llm.weight"), g("vae2llm.bias")
+        self.l2v_w, self.l2v_b = g("llm2vae.weight"), g("llm2vae.bias")
+        self.pos_embed = g("latent_pos_embed.pos_embed")
+        return self
+
+    @classmethod
+    def random(cls, dims: BagelDims, device, seed: int = 0, vocab_rows: Optional[int] = None) -> "MoTWeights":
+        """Random-init weights generated directly on the device in the fused layouts (benchmarks only:
+        no checkpoint exists offline).  Same distributions as bagel_amd.weights.make_llm_state_dict."""
+        from .weights import get_2d_sincos_pos_embed
+        self = cls(dims, device)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed)
+        H, I = dims.hidden_size, dims.intermediate_size
+        qkv = dims.q_dim + 2 * dims.kv_dim
+
+        def rn(shape, std, mean=0.0):
+            t = torch.empty(shape, device=device, dtype=BF16)
+            t.normal_(mean, std, generator=gen)
+            return t
+
+        for _ in range(dims.num_layers):
+            lw = LayerWeights([], [], [], [], [], [], [], [], [])
+            for _e in range(2):
+                lw.wqkv.append(rn((qkv, H), 0.02))
+                lw.bqkv.append(rn((qkv,), 0.02))
+                lw.wo.append(rn((H, dims.q_dim), 0.02))
+                lw.wgu.append(rn((2 * I, H), 0.02))
+                lw.wd.append(rn((H, I), 0.02))
+                lw.ln_in.append(rn((H,), 0.1, 1.0))
+                lw.ln_post.append(rn((H,), 0.1, 1.0))
+                lw.qn.append(rn((dims.head_dim,), 0.1, 1.0))
+                lw.kn.append(rn((dims.head_dim,), 0.1, 1.0))
+            self.layers.append(lw)
+        self.embed_tokens = rn((vocab_rows or dims.vocab_size, H), 0.02)
+        self.norm = [rn((H,), 0.1, 1.0), rn((H,), 0.1, 1.0)]
+        F = dims.timestep_freq_dim
+        self.t0_w, self.t0_b = rn((H, F), 0.02), rn((H,), 0.02)
+        self.t2_w, self.t2_b = rn((H, H), 0.02), rn((H,), 0.02)
+        P = dims.patch_latent_dim
+        self.v2l_w, self.v2l_b = rn((H, P), 0.02), rn((H,), 0.02)
+        self.l2v_w, self.l2v_b = rn((P, H), 0.8 / H ** 0.5), rn((P,), 0.02)
+        pe = get_2d_sincos_pos_embed(H, dims.max_latent_size)
+        self.pos_embed = torch.from_numpy(pe).float().to(BF16).to(device)
+        return self
+
+
+@dataclass
+class GenUnit:
+    """One (sample, CFG branch) pair of a flow step."""
+    sample: int                 # index into the packed batch
+    branch: int                 # 0 cond, 1 text-uncond, 2 image-uncond
+    ctx_len: int                # context tokens already in the KV cache
+    rope_pos: int               # RoPE position shared by all query tokens of the sample
+    ctx_k: Optional[List[torch.Tensor]] = None   # per layer [ctx_len, Hkv, D] (device, bf16) or None
+    ctx_v: Optional[List[torch.Tensor]] = None
+
+
+@dataclass
+class GenPlan:
+    units: List[GenUnit]
+    nv: List[int]               # latent tokens per unit
+    Mv: int
+    Mt: int
+    S: int
+    kv_start: List[int]
+    vae_row0: List[int]
+    row_cs: torch.Tensor
+    row_slot: torch.Tensor
+    src_row: torch.Tensor
+    tiles: torch.Tensor
+    n_tiles: int
+    cos: torch.Tensor
+    sin: torch.Tensor
+
+    @property
+    def M(self):
+        return self.Mv + self.Mt
+
+
+def rope_table(positions: Sequence[int], head_dim: int, theta: float, device):
+    """cos/sin rows for the given positions, rounded to bf16 (Qwen2RotaryEmbedding.forward,
+    modeling_qwen2.py:130-150; positions are constant over the flow steps so this runs once per image)."""
+    pos = torch.tensor(list(positions), dtype=torch.long)
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    freqs = (inv_freq[None, :, None].float() @ pos[None, None, :].float()).transpose(1, 2)[0]
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(BF16).to(device), emb.sin().to(BF16).to(device)
+
+
+class MoTEngine:
+    def __init__(self, dims: BagelDims, weights: MoTWeights, device):
+        assert dims.head_dim in (128,), "the attention kernel is built for head_dim 128"
+        self.dims = dims
+        self.w = weights
+        self.device = device
+        self._buf: Dict[str, torch.Tensor] = {}
+        self.kws = None
+        self.vtws = None
+
+    # ---- buffers --------------------------------------------------------------------------
+    def _get(self, name: str, shape, dtype=BF16, zero=False) -> torch.Tensor:
+        n = 1
+        for s in shape:
+            n *= s
+        cur = self._buf.get(name)
+        if cur is None or cur.numel() < n or cur.dtype != dtype:
+            cur = (torch.zeros if zero else torch.empty)(max(n, 1), device=self.device, dtype=dtype)
+            self._buf[name] = cur
+        return cur[:n].view(*shape)
+
+    # ---- planning -------------------------------------------------------------------------
+    def build_plan(self, units: List[GenUnit], sample_nv: Sequence[int], sample_row0: Sequence[int]) -> GenPlan:
+        """Row layout: latent rows of unit 0, unit 1, ... then two text rows per unit.
+        ``sample_row0[b]`` is the first row of sample b in the packed latent x_t."""
+        d = self.dims
+        nv = [sample_nv[u.sample] for u in units]
+        Mv, Mt = sum(nv), 2 * len(units)
+        kv_start, vae_row0 = [], []
+        s = r = 0
+        for u, n in zip(units, nv):
+            kv_start.append(s)
+            vae_row0.append(r)
+            s += (u.ctx_len + n + 2 + 63) // 64 * 64
+            r += n
+        S = s
+        row_cs = torch.empty(Mv + Mt, dtype=torch.int32)
+        row_slot = torch.empty(Mv + Mt, dtype=torch.int32)
+        src_row = torch.empty(Mv, dtype=torch.int32)
+        tiles = []
+        for i, (u, n) in enumerate(zip(units, nv)):
+            r0, ks = vae_row0[i], kv_start[i]
+            row_cs[r0:r0 + n] = i
+            row_slot[r0:r0 + n] = torch.arange(ks + u.ctx_len, ks + u.ctx_len + n, dtype=torch.int32)
+            src_row[r0:r0 + n] = torch.arange(sample_row0[u.sample], sample_row0[u.sample] + n, dtype=torch.int32)
+            t0 = Mv + 2 * i
+            row_cs[t0:t0 + 2] = i
+            row_slot[t0] = ks + u.ctx_len + n
+            row_slot[t0 + 1] = ks + u.ctx_len + n + 1
+            kv_len = u.ctx_len + n + 2
+            for q0 in range(0, n, 128):
+                tiles.append((r0 + q0, min(128, n - q0), ks, kv_len))
+            tiles.append((t0, 2, ks, kv_len))
+        cos, sin = rope_table([u.rope_pos for u in units], d.head_dim, d.rope_theta, self.device)
+        dev = self.device
+        return GenPlan(units, nv, Mv, Mt, S, kv_start, vae_row0, row_cs.to(dev), row_slot.to(dev), src_row.to(dev),
+                       torch.tensor(tiles, dtype=torch.int32).to(dev), len(tiles), cos, sin)
+
+    def load_context(self, plan: GenPlan):
+        """Allocate the KV workspace and copy every unit's context keys/values into it (once per image).
+        K [L][Hkv][S][D] row-major, Vt [L][Hkv][D][S] transposed; zero-filled so padding slots are finite."""
+        d = self.dims
+        L, Hkv, D, S = d.num_layers, d.num_kv_heads, d.head_dim, plan.S
+        self.kws = self._get("kws", (L, Hkv, S, D), zero=True)
+        self.vtws = self._get("vtws", (L, Hkv, D, S), zero=True)
+        self.kws.zero_()
+        self.vtws.zero_()
+        for u, ks in zip(plan.units, plan.kv_start):
+            if u.ctx_len == 0:
+                continue
+            for l in range(L):
+                self.kws[l, :, ks:ks + u.ctx_len, :].copy_(u.ctx_k[l].permute(1, 0, 2))
+                self.vtws[l, :, :, ks:ks + u.ctx_len].copy_(u.ctx_v[l].permute(1, 2, 0))
+
+    # ---- the forward ----------------------------------------------------------------------
+    def _und_rows(self, fn, Mt):
+        for r0 in range(0, Mt, 64):
+            fn(r0, min(64, Mt - r0))
+
+    def forward_gen(self, plan: GenPlan, x_bf16: torch.Tensor, temb: torch.Tensor, text_emb: torch.Tensor):
+        """x_bf16 [rows of the packed latent, P], temb [H], text_emb [Mt, H] -> velocities [Mv, P] (bf16),
+        rows in unit order.  Mirrors Bagel._forward_flow's embedding + forward_inference(mode="gen") +
+        llm2vae for all units at once (bagel.py:1389-1426, qwen2_navit.py:1041-1115)."""
+        d, w = self.dims, self.w
+        H, I, Hq, Hkv, D = d.hidden_size, d.intermediate_size, d.num_heads, d.num_kv_heads, d.head_dim
+        Mv, Mt, M = plan.Mv, plan.Mt, plan.M
+        qkv_dim = d.q_dim + 2 * d.kv_dim
+        X = self._get("X", (M, H))
+        Xn = self._get("Xn", (M, H))
+        QKV = self._get("QKV", (M, qkv_dim))
+        Q = self._get("Q", (M, d.q_dim))
+        O = self._get("O", (M, d.q_dim))
+        Hm = self._get("Hm", (M, I))
+        lin = self._get("lin", (x_bf16.shape[0], H))
+        Vout = self._get("Vout", (Mv, d.patch_latent_dim))
+        skw = self._get("skinny_ws", (16 * 64 * max(2 * I, qkv_dim),), dtype=torch.float32)
+        eps = d.rms_norm_eps
+
+        # embedding: vae2llm(x_t) + t_emb + pos_embed on latent rows, embed_tokens on text rows
+        K.gemm(x_bf16, w.v2l_w, lin, bias=w.v2l_b)
+        K.embed_latent(lin, temb, w.pos_embed, self._pos_id, plan.src_row, X, Mv)
+        K.gather_rows(text_emb, None, X[Mv:], Mt)
+
+        for l, lw in enumerate(w.layers):
+            kws, vtws = self.kws[l], self.vtws[l]
+            K.rmsnorm(X, Xn, lw.ln_in[0], lw.ln_in[1], Mv, eps)
+            K.gemm(Xn, lw.wqkv[0], QKV, bias=lw.bqkv[0], M=Mv)
+            self._und_rows(lambda r0, n: K.skinny_gemm(Xn[Mv + r0:Mv + r0 + n], lw.wqkv[1], QKV[Mv + r0:Mv + r0 + n],
+                                                       skw, bias=lw.bqkv[1]), Mt)
+            K.qk_norm_rope_kv(QKV, M, Hq, Hkv, D, lw.qn[0], lw.qn[1], lw.kn[0], lw.kn[1], Mv, plan.cos, plan.sin,
+                              plan.row_cs, plan.row_slot, Q, kws, vtws, plan.S, eps)
+            K.varlen_attention(Q, kws, vtws, O, plan.tiles, plan.n_tiles, Hq, Hkv, D, plan.S)
+            K.gemm(O, lw.wo[0], X, residual=X, epilogue=K.EPI_RESIDUAL, M=Mv)
+            self._und_rows(lambda r0, n: K.skinny_gemm(O[Mv + r0:Mv + r0 + n], lw.wo[1], X[Mv + r0:Mv + r0 + n], skw,
+                                                       residual=X[Mv + r0:Mv + r0 + n], epilogue=K.SK_RESIDUAL), Mt)
+            K.rmsnorm(X, Xn, lw.ln_post[0], lw.ln_post[1], Mv, eps)
+            K.gemm(Xn, lw.wgu[0], Hm, epilogue=K.EPI_SWIGLU, M=Mv)
+            self._und_rows(lambda r0, n: K.skinny_gemm(Xn[Mv + r0:Mv + r0 + n], lw.wgu[1], Hm[Mv + r0:Mv + r0 + n],
+                                                       skw, epilogue=K.SK_SWIGLU), Mt)
+            K.gemm(Hm, lw.wd[0], X, residual=X, epilogue=K.EPI_RESIDUAL, M=Mv)
+            self._und_rows(lambda r0, n: K.skinny_gemm(Hm[Mv + r0:Mv + r0 + n], lw.wd[1], X[Mv + r0:Mv + r0 + n], skw,
+                                                       residual=X[Mv + r0:Mv + r0 + n], epilogue=K.SK_RESIDUAL), Mt)
+
+        # final norm + llm2vae on the latent rows only (the text rows' outputs are never read, bagel.py:1426)
+        K.rmsnorm(X, Xn, w.norm[0], w.norm[1], Mv, eps, rows=Mv)
+        K.gemm(Xn, w.l2v_w, Vout, bias=w.l2v_b, M=Mv)
+        return Vout
+
+    def set_latent_position_ids(self, pos_ids: torch.Tensor):
+        self._pos_id = pos_ids.to(device=self.device, dtype=torch.int32)
+
+    # ---- timestep embedding table -----------------------------------------------------------
+    def timestep_table(self, timesteps: torch.Tensor) -> torch.Tensor:
+        """t_emb rows for every flow step at once (TimestepEmbedder.forward, modeling_utils.py:109-112).
+        The reference evaluates this MLP on Nv identical rows per step (bagel.py:1393-1395); here one row
+        per step, all steps in one weight-streaming pass."""
+        d, w = self.dims, self.w
+        n = timesteps.numel()
+        t_dev = timesteps.to(device=self.device, dtype=torch.float32).contiguous()
+        sin = self._get("t_sin", (n, d.timestep_freq_dim))
+        K.timestep_sinusoid(t_dev, sin)
+        h = self._get("t_h", (n, d.hidden_size))
+        out = torch.empty((n, d.hidden_size), device=self.device, dtype=BF16)
+        skw = self._get("skinny_ws_t", (16 * 64 * d.hidden_size,), dtype=torch.float32)
+        for r0 in range(0, n, 64):
+            m = min(64, n - r0)
+            K.skinny_gemm(sin[r0:r0 + m], w.t0_w, h[r0:r0 + m], skw, bias=w.t0_b, epilogue=K.SK_BIAS_SILU)
+            K.skinny_gemm(h[r0:r0 + m], w.t2_w, out[r0:r0 + m], skw, bias=w.t2_b)
+        return out

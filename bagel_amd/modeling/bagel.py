@@ -1,0 +1,390 @@
+"""``Bagel``: the reference's generation API (modeling/bagel/bagel.py:806-1500) over the HIP engine.
+
+Method names, argument names and meanings, return values and error behaviour follow the reference so
+that ``InterleaveInferencer`` and the evaluation drivers can call this class unchanged.  What differs is
+underneath: all CFG branches of a step run as one packed forward, the KV context lives in a persistent
+workspace that is filled once per image, and ``x_t`` stays on the device.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import _lib as K
+from ..config import BagelDims
+from ..engine import GenUnit, MoTEngine, MoTWeights
+
+BF16 = torch.bfloat16
+
+
+class NaiveCache:
+    """Per-layer packed context keys/values, ``[total_ctx_tokens, Hkv, D]`` bf16; ``None`` = empty context
+    (reference: qwen2_navit.py:214-228)."""
+
+    def __init__(self, num_layers):
+        self.key_cache = {k: None for k in range(num_layers)}
+        self.value_cache = {k: None for k in range(num_layers)}
+
+    @property
+    def num_layers(self):
+        return len(self.key_cache)
+
+    @property
+    def seq_lens(self):
+        if self.key_cache[0] is not None:
+            return self.key_cache[0].shape[0]
+        return 0
+
+
+def get_flattened_position_ids_extrapolate(img_h, img_w, patch_size, max_num_patches_per_side):
+    """data/data_utils.py:53-58."""
+    nh, nw = img_h // patch_size, img_w // patch_size
+    return (torch.arange(0, nh)[:, None] * max_num_patches_per_side + torch.arange(0, nw)).flatten()
+
+
+class _LLMConfig:
+    def __init__(self, dims: BagelDims):
+        self.num_hidden_layers = dims.num_layers
+        self.hidden_size = dims.hidden_size
+        self.num_attention_heads = dims.num_heads
+        self.num_key_value_heads = dims.num_kv_heads
+        self.intermediate_size = dims.intermediate_size
+        self.layer_module = "Qwen2MoTDecoderLayer"
+
+
+class _Config:
+    def __init__(self, dims: BagelDims):
+        self.llm_config = _LLMConfig(dims)
+        self.latent_patch_size = dims.latent_patch_size
+        self.max_latent_size = dims.max_latent_size
+
+
+class Bagel:
+    def __init__(self, dims: BagelDims, state_dict: Optional[Dict[str, torch.Tensor]] = None, device="cuda:0",
+                 weights: Optional[MoTWeights] = None):
+        K.lib()  # fail loudly when the HIP extension is missing
+        self.dims = dims
+        self.device = torch.device(device)
+        if weights is None:
+            if state_dict is None:
+                raise ValueError("Bagel needs a state dict (reference parameter names) or prepared MoTWeights")
+            weights = MoTWeights.from_state_dict(dims, state_dict, self.device)
+        self.engine = MoTEngine(dims, weights, self.device)
+        self.config = _Config(dims)
+        self.hidden_size = dims.hidden_size
+        self.use_moe = True
+        self.num_heads = dims.num_heads
+        self.latent_patch_size = dims.latent_patch_size
+        self.latent_downsample = dims.latent_downsample
+        self.max_latent_size = dims.max_latent_size
+        self.latent_channel = dims.latent_channel
+        self.patch_latent_dim = dims.patch_latent_dim
+        self.get_flattened_position_ids = get_flattened_position_ids_extrapolate
+        # set by generate_image for inspection by tests / callers
+        self.last_step_velocities: Optional[dict] = None
+
+    def parameters(self):
+        yield self.engine.w.embed_tokens
+
+    def eval(self):
+        return self
+
+    # ------------------------------------------------------------------------------------------
+    # host index builders (bit-for-bit the reference's lists, incl. the CPU RNG draw order)
+    # ------------------------------------------------------------------------------------------
+    def prepare_vae_latent(self, curr_kvlens, curr_rope, image_sizes, new_token_ids):
+        """bagel.py:1145-1201."""
+        packed_text_ids, packed_text_indexes = [], []
+        packed_vae_position_ids, packed_vae_token_indexes, packed_init_noises = [], [], []
+        packed_position_ids, packed_seqlens, packed_indexes = [], [], []
+        packed_key_value_indexes = []
+        query_curr = curr = 0
+        for (H, W), curr_kvlen, curr_position_id in zip(image_sizes, curr_kvlens, curr_rope):
+            packed_key_value_indexes.extend(range(curr, curr + curr_kvlen))
+            curr += curr_kvlen
+            packed_text_ids.append(new_token_ids["start_of_image"])
+            packed_text_indexes.append(query_curr)
+            packed_indexes.append(curr)
+            curr += 1
+            query_curr += 1
+            packed_vae_position_ids.append(self.get_flattened_position_ids(
+                H, W, self.latent_downsample, max_num_patches_per_side=self.max_latent_size))
+            h, w = H // self.latent_downsample, W // self.latent_downsample
+            num_image_tokens = h * w
+            packed_init_noises.append(torch.randn(num_image_tokens, self.latent_channel * self.latent_patch_size ** 2))
+            packed_vae_token_indexes.extend(range(query_curr, query_curr + num_image_tokens))
+            packed_indexes.extend(range(curr, curr + num_image_tokens))
+            curr += num_image_tokens
+            query_curr += num_image_tokens
+            packed_text_ids.append(new_token_ids["end_of_image"])
+            packed_text_indexes.append(query_curr)
+            packed_indexes.append(curr)
+            curr += 1
+            query_curr += 1
+            packed_position_ids.extend([curr_position_id] * (num_image_tokens + 2))
+            packed_seqlens.append(num_image_tokens + 2)
+        return {
+            "packed_text_ids": torch.tensor(packed_text_ids, dtype=torch.long),
+            "packed_text_indexes": torch.tensor(packed_text_indexes, dtype=torch.long),
+            "packed_init_noises": torch.cat(packed_init_noises, dim=0),
+            "packed_vae_position_ids": torch.cat(packed_vae_position_ids, dim=0),
+            "packed_vae_token_indexes": torch.tensor(packed_vae_token_indexes, dtype=torch.long),
+            "packed_seqlens": torch.tensor(packed_seqlens, dtype=torch.int),
+            "packed_position_ids": torch.tensor(packed_position_ids, dtype=torch.long),
+            "key_values_lens": torch.tensor(curr_kvlens, dtype=torch.int),
+            "packed_indexes": torch.tensor(packed_indexes, dtype=torch.long),
+            "packed_key_value_indexes": torch.tensor(packed_key_value_indexes, dtype=torch.long),
+        }
+
+    def prepare_vae_latent_cfg(self, curr_kvlens, curr_rope, image_sizes):
+        """bagel.py:1203-1234."""
+        packed_position_ids, packed_indexes, packed_key_value_indexes = [], [], []
+        curr = 0
+        for (H, W), curr_kvlen, curr_position_id in zip(image_sizes, curr_kvlens, curr_rope):
+            packed_key_value_indexes.extend(range(curr, curr + curr_kvlen))
+            curr += curr_kvlen
+            n = (H // self.latent_downsample) * (W // self.latent_downsample)
+            packed_indexes.extend(range(curr, curr + n + 2))
+            curr += n + 2
+            packed_position_ids.extend([curr_position_id] * (n + 2))
+        return {
+            "cfg_packed_position_ids": torch.tensor(packed_position_ids, dtype=torch.long),
+            "cfg_key_values_lens": torch.tensor(curr_kvlens, dtype=torch.int),
+            "cfg_packed_query_indexes": torch.tensor(packed_indexes, dtype=torch.long),
+            "cfg_packed_key_value_indexes": torch.tensor(packed_key_value_indexes, dtype=torch.long),
+        }
+
+    # ------------------------------------------------------------------------------------------
+    # translation of the packed-index API into engine units
+    # ------------------------------------------------------------------------------------------
+    def _check_packing(self, seqlens: List[int], text_indexes, vae_indexes):
+        """The engine relies on the canonical per-sample layout [soi, latent tokens, eoi] that
+        prepare_vae_latent produces (bagel.py:1156-1186)."""
+        t, v = [], []
+        q = 0
+        for n in seqlens:
+            t += [q, q + n - 1]
+            v += list(range(q + 1, q + n - 1))
+            q += n
+        if text_indexes.tolist() != t or vae_indexes.tolist() != v:
+            raise NotImplementedError("packed_text_indexes / packed_vae_token_indexes do not follow the "
+                                      "[start_of_image, latent tokens, end_of_image] layout of prepare_vae_latent")
+
+    def _branch_units(self, branch: int, seqlens: List[int], position_ids, query_indexes, past: Optional[NaiveCache],
+                      kv_lens, kv_indexes) -> List[GenUnit]:
+        """Per-sample units of one CFG branch from the reference's packed description of that branch
+        (position ids, query slots, context lengths, context slots; bagel.py:1413-1464)."""
+        kvl = [int(x) for x in kv_lens.tolist()]
+        pos = position_ids.tolist()
+        qi = query_indexes.tolist()
+        ki = kv_indexes.tolist()
+        units = []
+        q = c = tot = 0
+        for b, n in enumerate(seqlens):
+            sample_pos = pos[q:q + n]
+            if any(p != sample_pos[0] for p in sample_pos):
+                raise NotImplementedError("query tokens of one image must share one RoPE position (bagel.py:1185)")
+            # merged layout must be [context of sample b | queries of sample b] (qwen2_navit.py:574-581)
+            if ki[c:c + kvl[b]] != list(range(tot, tot + kvl[b])) or qi[q:q + n] != list(range(tot + kvl[b], tot + kvl[b] + n)):
+                raise NotImplementedError("packed_indexes / packed_key_value_indexes are not the contiguous "
+                                          "per-sample layout produced by prepare_vae_latent")
+            u = GenUnit(sample=b, branch=branch, ctx_len=kvl[b], rope_pos=int(sample_pos[0]))
+            if kvl[b] > 0:
+                if past is None or past.key_cache[0] is None:
+                    raise ValueError("key_values_lens > 0 but the NaiveCache is empty")
+                u.ctx_k = [past.key_cache[l][c:c + kvl[b]].to(self.device, BF16) for l in range(self.dims.num_layers)]
+                u.ctx_v = [past.value_cache[l][c:c + kvl[b]].to(self.device, BF16) for l in range(self.dims.num_layers)]
+            units.append(u)
+            q += n
+            c += kvl[b]
+            tot += kvl[b] + n
+        if past is not None and past.key_cache[0] is not None and past.key_cache[0].shape[0] != c:
+            raise ValueError("NaiveCache length does not match key_values_lens")
+        return units
+
+    # ------------------------------------------------------------------------------------------
+    # sampler
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate_image(
+        self,
+        packed_text_ids: torch.LongTensor,
+        packed_text_indexes: torch.LongTensor,
+        packed_init_noises: torch.Tensor,
+        packed_vae_position_ids: torch.LongTensor,
+        packed_vae_token_indexes: torch.LongTensor,
+        packed_seqlens: torch.IntTensor,
+        packed_position_ids: torch.LongTensor,
+        packed_indexes: torch.LongTensor,
+        past_key_values: NaiveCache,
+        key_values_lens: torch.IntTensor,
+        packed_key_value_indexes: torch.LongTensor,
+        num_timesteps: int = 24,
+        timestep_shift: float = 1.0,
+        cfg_renorm_min: float = 0.0,
+        cfg_renorm_type: str = "global",
+        cfg_interval: Optional[Tuple[float, float]] = [0, 1],
+        # cfg_text
+        cfg_text_scale: float = 1.0,
+        cfg_text_packed_query_indexes: Optional[torch.LongTensor] = None,
+        cfg_text_packed_position_ids: Optional[torch.LongTensor] = None,
+        cfg_text_past_key_values: Optional[NaiveCache] = None,
+        cfg_text_key_values_lens: Optional[torch.IntTensor] = None,
+        cfg_text_packed_key_value_indexes: Optional[torch.LongTensor] = None,
+        # cfg_img
+        cfg_img_scale: float = 1.0,
+        cfg_img_packed_query_indexes: Optional[torch.LongTensor] = None,
+        cfg_img_packed_position_ids: Optional[torch.LongTensor] = None,
+        cfg_img_past_key_values: Optional[NaiveCache] = None,
+        cfg_img_key_values_lens: Optional[torch.IntTensor] = None,
+        cfg_img_packed_key_value_indexes: Optional[torch.LongTensor] = None,
+        cfg_type: str = "parallel",
+        # cache_args
+        enable_taylorseer=False,
+        # additions (not in the reference): stop after this many Euler steps; collect per-step tensors
+        max_steps: Optional[int] = None,
+        trace: Optional[list] = None,
+        teacher_x: Optional[Sequence[torch.Tensor]] = None,
+    ):
+        """Bagel.generate_image (bagel.py:1237-1347).  Returns a tuple of per-image ``[Nv, 64]`` fp32 latents
+        (on the device).  ``enable_taylorseer`` changes results by design and is not offered here."""
+        if enable_taylorseer:
+            raise NotImplementedError("TaylorSeer step skipping is an approximation and is not implemented")
+        if cfg_renorm_type not in K.RENORM and cfg_text_scale > 1.0:
+            raise NotImplementedError(f"{cfg_renorm_type} is not suppoprted")
+        eng, d, dev = self.engine, self.dims, self.device
+        cpu = lambda t: t.detach().cpu()  # noqa: E731
+        seqlens = [int(x) for x in cpu(packed_seqlens).tolist()]
+        self._check_packing(seqlens, cpu(packed_text_indexes), cpu(packed_vae_token_indexes))
+        sample_nv = [n - 2 for n in seqlens]
+        sample_row0 = [sum(sample_nv[:b]) for b in range(len(seqlens))]
+        Nv = sum(sample_nv)
+
+        use_text = cfg_text_scale > 1.0
+        use_img = use_text and cfg_img_scale > 1.0   # image CFG only acts inside the text-CFG branch (bagel.py:1466-1483)
+        units = self._branch_units(0, seqlens, cpu(packed_position_ids), cpu(packed_indexes), past_key_values,
+                                   cpu(key_values_lens), cpu(packed_key_value_indexes))
+        n_cond = len(units)
+        if use_text:
+            units += self._branch_units(1, seqlens, cpu(cfg_text_packed_position_ids), cpu(cfg_text_packed_query_indexes),
+                                        cfg_text_past_key_values, cpu(cfg_text_key_values_lens),
+                                        cpu(cfg_text_packed_key_value_indexes))
+        if use_img:
+            units += self._branch_units(2, seqlens, cpu(cfg_img_packed_position_ids), cpu(cfg_img_packed_query_indexes),
+                                        cfg_img_past_key_values, cpu(cfg_img_key_values_lens),
+                                        cpu(cfg_img_packed_key_value_indexes))
+
+        plan_full = eng.build_plan(units, sample_nv, sample_row0)
+        eng.load_context(plan_full)
+        # steps outside cfg_interval run the cond branch only; its units are the first rows/slots of the full plan
+        plan_cond = eng.build_plan(units[:n_cond], sample_nv, sample_row0) if len(units) > n_cond else plan_full
+        plan_cond.S = plan_full.S  # same workspace, same strides; the cond units own its first slots
+        for u in units:
+            u.ctx_k = u.ctx_v = None  # context now lives in the workspace
+        eng.set_latent_position_ids(cpu(packed_vae_position_ids))
+
+        # text rows: embed_tokens([soi, eoi]) per unit, constant over steps (bagel.py:1389-1391)
+        ids = cpu(packed_text_ids).to(torch.int32)
+        nb = len(seqlens)
+        text_emb = {}
+        for plan in {id(plan_full): plan_full, id(plan_cond): plan_cond}.values():
+            idx = torch.cat([ids[2 * u.sample:2 * u.sample + 2] for u in plan.units]).to(dev)
+            te = torch.empty((plan.Mt, d.hidden_size), device=dev, dtype=BF16)
+            K.gather_rows(eng.w.embed_tokens, idx, te, plan.Mt)
+            text_emb[id(plan)] = te
+
+        # timesteps exactly as the reference builds them, in fp32 on the host (bagel.py:1286-1289)
+        timesteps = torch.linspace(1, 0, num_timesteps)
+        timesteps = timestep_shift * timesteps / (1 + (timestep_shift - 1) * timesteps)
+        dts = timesteps[:-1] - timesteps[1:]
+        timesteps = timesteps[:-1]
+        temb_table = eng.timestep_table(timesteps)
+
+        x_t = packed_init_noises.to(device=dev, dtype=torch.float32).clone().contiguous()
+        x_bf16 = torch.empty((Nv, d.patch_latent_dim), device=dev, dtype=BF16)
+        K.cast_f32_bf16(x_t, x_bf16)
+        v_t = torch.empty((Nv, d.patch_latent_dim), device=dev, dtype=BF16)
+        cfg_ws = torch.empty(K.cfg_workspace_bytes(Nv, d.patch_latent_dim), device=dev, dtype=torch.uint8)
+
+        for i, t in enumerate(timesteps.tolist()):
+            if max_steps is not None and i >= max_steps:
+                break
+            if teacher_x is not None:
+                x_t.copy_(teacher_x[i].to(dev, torch.float32))
+                K.cast_f32_bf16(x_t, x_bf16)
+            active = t > cfg_interval[0] and t <= cfg_interval[1]
+            ts_, is_ = (cfg_text_scale, cfg_img_scale) if active else (1.0, 1.0)
+            plan = plan_full if (active and use_text) else plan_cond
+            vout = eng.forward_gen(plan, x_bf16, temb_table[i], text_emb[id(plan)])
+            v_cond = vout[:Nv]
+            v_text = vout[Nv:2 * Nv] if (active and use_text) else None
+            v_img = vout[2 * Nv:3 * Nv] if (active and use_img) else None
+            if trace is not None:
+                rec = {"x_t": x_t.clone(), "v_cond": v_cond.clone()}
+                if v_text is not None:
+                    rec["v_text"] = v_text.clone()
+                if v_img is not None:
+                    rec["v_img"] = v_img.clone()
+            K.cfg_euler_update(v_cond, v_text, v_img, ts_, is_, cfg_renorm_type, cfg_renorm_min, float(dts[i]),
+                               x_t, x_bf16, v_t, cfg_ws)
+            if trace is not None:
+                rec["v_t"] = v_t.clone()
+                trace.append(rec)
+
+        return x_t.split(sample_nv)
+
+    @torch.no_grad()
+    def _forward_flow(self, x_t, timestep, packed_vae_token_indexes, packed_vae_position_ids, packed_text_ids,
+                      packed_text_indexes, packed_indexes, packed_position_ids, packed_seqlens, key_values_lens,
+                      past_key_values, packed_key_value_indexes, cfg_renorm_min=0.0, cfg_renorm_type="global",
+                      cfg_text_scale=1.0, cfg_text_packed_position_ids=None, cfg_text_packed_query_indexes=None,
+                      cfg_text_key_values_lens=None, cfg_text_past_key_values=None,
+                      cfg_text_packed_key_value_indexes=None, cfg_img_scale=1.0, cfg_img_packed_position_ids=None,
+                      cfg_img_packed_query_indexes=None, cfg_img_key_values_lens=None, cfg_img_past_key_values=None,
+                      cfg_img_packed_key_value_indexes=None, cfg_type="parallel", **unused_cache_args):
+        """Bagel._forward_flow (bagel.py:1350-1500): the CFG-combined velocity for one timestep.
+        Standalone use re-stages the KV context on every call; generate_image does it once per image."""
+        tt = timestep.detach().float().cpu()
+        assert tt.unique().shape[0] == 1
+        eng, d, dev = self.engine, self.dims, self.device
+        cpu = lambda t: t.detach().cpu()  # noqa: E731
+        seqlens = [int(x) for x in cpu(packed_seqlens).tolist()]
+        self._check_packing(seqlens, cpu(packed_text_indexes), cpu(packed_vae_token_indexes))
+        sample_nv = [n - 2 for n in seqlens]
+        sample_row0 = [sum(sample_nv[:b]) for b in range(len(seqlens))]
+        Nv = sum(sample_nv)
+        use_text = cfg_text_scale > 1.0
+        use_img = use_text and cfg_img_scale > 1.0
+        if use_text and cfg_renorm_type not in K.RENORM:
+            raise NotImplementedError(f"{cfg_renorm_type} is not suppoprted")
+        units = self._branch_units(0, seqlens, cpu(packed_position_ids), cpu(packed_indexes), past_key_values,
+                                   cpu(key_values_lens), cpu(packed_key_value_indexes))
+        if use_text:
+            units += self._branch_units(1, seqlens, cpu(cfg_text_packed_position_ids), cpu(cfg_text_packed_query_indexes),
+                                        cfg_text_past_key_values, cpu(cfg_text_key_values_lens),
+                                        cpu(cfg_text_packed_key_value_indexes))
+        if use_img:
+            units += self._branch_units(2, seqlens, cpu(cfg_img_packed_position_ids), cpu(cfg_img_packed_query_indexes),
+                                        cfg_img_past_key_values, cpu(cfg_img_key_values_lens),
+                                        cpu(cfg_img_packed_key_value_indexes))
+        plan = eng.build_plan(units, sample_nv, sample_row0)
+        eng.load_context(plan)
+        eng.set_latent_position_ids(cpu(packed_vae_position_ids))
+        ids = cpu(packed_text_ids).to(torch.int32)
+        idx = torch.cat([ids[2 * u.sample:2 * u.sample + 2] for u in plan.units]).to(dev)
+        text_emb = torch.empty((plan.Mt, d.hidden_size), device=dev, dtype=BF16)
+        K.gather_rows(eng.w.embed_tokens, idx, text_emb, plan.Mt)
+        temb = eng.timestep_table(tt[:1])
+        x = x_t.to(device=dev, dtype=torch.float32).clone().contiguous()
+        x_bf16 = torch.empty((Nv, d.patch_latent_dim), device=dev, dtype=BF16)
+        K.cast_f32_bf16(x, x_bf16)
+        vout = eng.forward_gen(plan, x_bf16, temb[0], text_emb)
+        v_t = torch.empty((Nv, d.patch_latent_dim), device=dev, dtype=BF16)
+        cfg_ws = torch.empty(K.cfg_workspace_bytes(Nv, d.patch_latent_dim), device=dev, dtype=torch.uint8)
+        K.cfg_euler_update(vout[:Nv], vout[Nv:2 * Nv] if use_text else None, vout[2 * Nv:3 * Nv] if use_img else None,
+                           cfg_text_scale, cfg_img_scale, cfg_renorm_type, cfg_renorm_min, 0.0, x, x_bf16, v_t, cfg_ws)
+        self.last_step_velocities = {"v_cond": vout[:Nv].clone(),
+                                     "v_text": vout[Nv:2 * Nv].clone() if use_text else None,
+                                     "v_img": vout[2 * Nv:3 * Nv].clone() if use_img else None}
+        return v_t

@@ -1,0 +1,100 @@
+/* C ABI of libbagel_hip.so: the gfx950 (MI355X) kernels behind BAGEL's image-generation hot path.
+ *
+ * The reference has no FFI of its own: its hot path is Python methods on nn.Modules that call
+ * torch / flash_attn library kernels.  Each entry point below replaces the library call(s) made at the
+ * cited reference lines.  Conventions:
+ *   - every pointer is a DEVICE pointer unless named otherwise; nothing is allocated or freed here;
+ *   - bf16 tensors are row-major with element (not byte) leading dimensions;
+ *   - `stream` is a hipStream_t; kernels are enqueued and the call returns immediately;
+ *   - return 0 on success, non-zero on failure, message from bagel_last_error() (thread-local).
+ */
+#ifndef BAGEL_HIP_H
+#define BAGEL_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int bagel_abi_version(void);
+const char* bagel_last_error(void);
+
+/* epilogues of bagel_gemm_bf16 */
+#define BAGEL_EPI_BIAS 0     /* C = bf16(acc + bias)  (bias may be NULL) */
+#define BAGEL_EPI_RESIDUAL 1 /* C = bf16(bf16(acc) + R) */
+#define BAGEL_EPI_SWIGLU 2   /* C[:, f] = bf16(bf16(silu(bf16(gate_f))) * bf16(up_f)); W rows interleaved
+                                [16 gate rows | 16 up rows] per 16 features; C has N/2 columns */
+
+/* C[M,N] = epilogue(A[M,K] . W[N,K]^T), bf16 operands, fp32 accumulation on the MFMA units.
+ * Replaces the nn.Linear calls of the generation expert: q/k/v_proj_moe_gen (qwen2_navit.py:541-547),
+ * o_proj_moe_gen (:605), mlp_moe_gen gate/up/down (:833, modeling_qwen2.py:200-201), vae2llm and
+ * llm2vae (bagel.py:1396,1425), and the residual adds (:818,836).  K % 64 == 0, N % 4 == 0. */
+int bagel_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
+                    const void* bias, const void* residual, long ldr, int epilogue, void* stream);
+
+/* epilogues of bagel_skinny_gemm_bf16 */
+#define BAGEL_SK_BIAS 0
+#define BAGEL_SK_RESIDUAL 1
+#define BAGEL_SK_SWIGLU 2
+#define BAGEL_SK_BIAS_SILU 3 /* C = bf16(silu(bf16(acc + bias))) */
+
+/* Same contraction for M <= 64 rows, streaming every weight byte once (HBM-bound).
+ * Replaces the understanding expert's nn.Linear calls on the two text tokens of each sample
+ * (qwen2_navit.py:540,543,546,604,832) and TimestepEmbedder.mlp (modeling_utils.py:80-84,111).
+ * N % 16 == 0, K % 128 == 0.  `workspace` holds fp32 split-K partials. */
+long bagel_skinny_gemm_workspace_bytes(int M, int N);
+int bagel_skinny_gemm_bf16(const void* X, long ldx, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
+                           const void* bias, const void* residual, long ldr, int epilogue, void* workspace,
+                           long workspace_bytes, void* stream);
+
+/* out[r] = w * bf16(x[r] * rsqrt(mean(x[r]^2) + eps)); rows < split_row use w_first, the rest w_second.
+ * Replaces Qwen2RMSNorm (modeling_qwen2.py:54-59) as used per modality at qwen2_navit.py:798-800,
+ * 826-829 and 1102-1104. */
+int bagel_rmsnorm_bf16(const void* x, long ldx, void* out, long ldo, int rows, int H, const void* w_first,
+                       const void* w_second, int split_row, float eps, void* stream);
+
+/* Per-head RMSNorm of q and k + RoPE + scatter of q, k, v into the attention operands.
+ * Replaces qwen2_navit.py:549-585: the fp32 q/k norms per modality, apply_rotary_pos_emb, the bf16 casts
+ * and the per-layer rebuild of merged_key_states / merged_value_states.
+ *   qkv      [M][(Hq+2Hkv)*D]  fused projection output (q heads, k heads, v heads)
+ *   row_cs   [M] int32         row of cos_table / sin_table ([*][D] bf16) for each token
+ *   row_slot [M] int32         key slot of each token in the KV workspace
+ *   Q        [M][Hq][D]        K_ws [Hkv][S][D]        Vt_ws [Hkv][D][S]
+ * und_rounding != 0 follows the understanding-mode graph (:526-530: bf16 norm output, bf16 RoPE). */
+int bagel_qk_norm_rope_kv_bf16(const void* qkv, long ld, int M, int Hq, int Hkv, int head_dim,
+                               const void* q_norm_first, const void* q_norm_second, const void* k_norm_first,
+                               const void* k_norm_second, int split_row, const void* cos_table,
+                               const void* sin_table, const void* row_cs, const void* row_slot, void* Q, void* K_ws,
+                               void* Vt_ws, long S, float eps, int und_rounding, void* stream);
+
+/* Packed varlen GQA attention, non-causal: replaces flash_attn_varlen_func (qwen2_navit.py:590-599).
+ *   tiles [n_tiles] of {int q_row0, n_rows (<=128), kv_start (multiple of 64), kv_len}
+ * Every query row of a tile attends key slots [kv_start, kv_start + kv_len) of its kv head. */
+int bagel_varlen_attention_bf16(const void* Q, const void* K_ws, const void* Vt_ws, void* O, const void* tiles,
+                                int n_tiles, int Hq, int Hkv, int head_dim, long S, void* stream);
+
+/* X[r] = bf16(bf16(lin[src_row[r]] + temb) + pos_table[pos_id[src_row[r]]]): bagel.py:1394-1399. */
+int bagel_embed_latent_bf16(const void* lin, long ldl, const void* temb, const void* pos_table, const void* pos_id,
+                            const void* src_row, void* X, long ldx, int rows, int H, void* stream);
+
+/* out[r] = table[idx[r]] (idx == NULL: identity): embed_tokens lookup, bagel.py:1389-1391. */
+int bagel_gather_rows_bf16(const void* table, long ldt, const void* idx, void* out, long ldo, int rows, int H,
+                           void* stream);
+
+/* out[i] = [cos(t_i f) | sin(t_i f)], f_k = exp(-ln(1e4) k / (dim/2)): modeling_utils.py:88-107. */
+int bagel_timestep_sinusoid_bf16(const void* t, int n, int dim, void* out, void* stream);
+
+int bagel_cast_f32_bf16(const void* x, void* out, long n, void* stream);
+
+/* CFG combine + renorm + Euler update: bagel.py:1466-1500 and :1339.
+ *   renorm_type 0 "global", 1 "channel", 2 "text_channel"; v_* are [rows][P] bf16 (P == 64);
+ *   x_t fp32 [rows][P] is updated in place: x_t -= bf16(v_t * dt); x_bf16 receives bf16(x_t);
+ *   v_t_out (optional) receives the combined velocity.  CFG is applied iff cfg_text_scale > 1. */
+long bagel_cfg_workspace_bytes(int rows, int P);
+int bagel_cfg_euler_update(const void* v_cond, const void* v_text, const void* v_img, float cfg_text_scale,
+                           float cfg_img_scale, int renorm_type, float renorm_min, float dt, void* x_t, void* x_bf16,
+                           void* v_t_out, int rows, int P, void* workspace, long workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BAGEL_HIP_H */

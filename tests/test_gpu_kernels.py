@@ -1,0 +1,269 @@
+"""Kernel-level parity: each C-ABI entry point against the CPU checker's restatement of the same op.
+
+bf16 outputs are compared after both sides round at the same points, so the tolerance is a couple of bf16
+ulps of the largest magnitude (2^-8 relative each) plus fp32 accumulation-order noise.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bagel_oracle as O  # noqa: E402
+
+BF16 = torch.bfloat16
+DEV = "cuda:0"
+
+
+def _K():
+    from bagel_amd import _lib
+    return _lib
+
+
+def _rand(shape, std=1.0, seed=0, dtype=BF16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * std).to(dtype)
+
+
+def _close(got, ref, ulps=2.0, what=""):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    tol = ulps * 2.0 ** -8 * float(ref.abs().max()) + 1e-6
+    err = float((got - ref).abs().max())
+    assert err <= tol, f"{what}: max-abs {err} > {tol}"
+    # and almost all elements must agree to one ulp of their own magnitude
+    rel = (got - ref).abs() <= (2.0 ** -7 * ref.abs() + 1e-3 * float(ref.abs().max()))
+    assert rel.float().mean() > 0.999, f"{what}: only {rel.float().mean():.4f} of elements within 1 ulp"
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 512, 256), (130, 384, 192), (4096, 4608, 3584),
+                                   (64, 64, 3584), (1000, 3584, 64), (4098, 64, 256)])
+def test_gemm_bias(M, N, K):
+    k = _K()
+    A, W, b = _rand((M, K), 1.0, 1), _rand((N, K), 0.05, 2), _rand((N,), 0.5, 3)
+    C = torch.full((M, N), float("nan"), dtype=BF16, device=DEV)
+    k.gemm(A.to(DEV), W.to(DEV), C, bias=b.to(DEV))
+    ref = (A.float() @ W.float().t() + b.float()).to(BF16)
+    _close(C, ref, what=f"gemm bias {M}x{N}x{K}")
+    C2 = torch.full((M, N), float("nan"), dtype=BF16, device=DEV)
+    k.gemm(A.to(DEV), W.to(DEV), C2)
+    _close(C2, (A.float() @ W.float().t()).to(BF16), what="gemm nobias")
+
+
+def test_gemm_asymmetric_layout():
+    """A = identity against an asymmetric W: catches a transposed or permuted C write."""
+    k = _K()
+    n = 256
+    A = torch.eye(n, dtype=BF16)
+    W = (torch.arange(n * n).reshape(n, n) % 251).to(BF16) / 8
+    C = torch.empty((n, n), dtype=BF16, device=DEV)
+    k.gemm(A.to(DEV), W.to(DEV), C)
+    assert torch.equal(C.cpu(), W.t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 3584, 512), (4096, 3584, 3584)])
+def test_gemm_residual_inplace(M, N, K):
+    k = _K()
+    A, W, R = _rand((M, K), 1.0, 4), _rand((N, K), 0.05, 5), _rand((M, N), 1.0, 6)
+    X = R.to(DEV).clone()
+    k.gemm(A.to(DEV), W.to(DEV), X, residual=X, epilogue=k.EPI_RESIDUAL)
+    ref = ((A.float() @ W.float().t()).to(BF16).float() + R.float()).to(BF16)
+    _close(X, ref, what="gemm residual")
+
+
+@pytest.mark.parametrize("M,I,K", [(128, 512, 256), (200, 2304, 1792), (4096, 18944, 3584)])
+def test_gemm_swiglu(M, I, K):
+    k = _K()
+    from bagel_amd.engine import _interleave_gate_up
+    A, G, U = _rand((M, K), 1.0, 7), _rand((I, K), 0.03, 8), _rand((I, K), 0.03, 9)
+    Wgu = _interleave_gate_up(G, U).to(DEV)
+    C = torch.empty((M, I), dtype=BF16, device=DEV)
+    k.gemm(A.to(DEV), Wgu, C, epilogue=k.EPI_SWIGLU)
+    g = (A.float() @ G.float().t()).to(BF16)
+    u = (A.float() @ U.float().t()).to(BF16)
+    ref = torch.nn.functional.silu(g) * u
+    _close(C, ref, ulps=3.0, what="gemm swiglu")
+
+
+@pytest.mark.parametrize("M", [1, 2, 6, 16, 17, 48, 64])
+@pytest.mark.parametrize("N,K", [(512, 256), (4608, 3584), (3584, 18944)])
+def test_skinny_gemm(M, N, K):
+    k = _K()
+    X, W, b = _rand((M, K), 1.0, 10), _rand((N, K), 0.03, 11), _rand((N,), 0.5, 12)
+    ws = torch.empty(k.skinny_workspace_bytes(M, N), dtype=torch.uint8, device=DEV)
+    C = torch.full((M, N), float("nan"), dtype=BF16, device=DEV)
+    k.skinny_gemm(X.to(DEV), W.to(DEV), C, ws, bias=b.to(DEV))
+    _close(C, (X.float() @ W.float().t() + b.float()).to(BF16), what="skinny bias")
+    R = _rand((M, N), 1.0, 13)
+    Xr = R.to(DEV).clone()
+    k.skinny_gemm(X.to(DEV), W.to(DEV), Xr, ws, residual=Xr, epilogue=k.SK_RESIDUAL)
+    _close(Xr, ((X.float() @ W.float().t()).to(BF16).float() + R.float()).to(BF16), what="skinny residual")
+    C3 = torch.empty((M, N), dtype=BF16, device=DEV)
+    k.skinny_gemm(X.to(DEV), W.to(DEV), C3, ws, bias=b.to(DEV), epilogue=k.SK_BIAS_SILU)
+    _close(C3, torch.nn.functional.silu((X.float() @ W.float().t() + b.float()).to(BF16)), ulps=3.0, what="skinny silu")
+
+
+def test_skinny_swiglu():
+    k = _K()
+    from bagel_amd.engine import _interleave_gate_up
+    M, I, Kd = 6, 2304, 1792
+    X, G, U = _rand((M, Kd), 1.0, 14), _rand((I, Kd), 0.03, 15), _rand((I, Kd), 0.03, 16)
+    ws = torch.empty(k.skinny_workspace_bytes(M, 2 * I), dtype=torch.uint8, device=DEV)
+    C = torch.empty((M, I), dtype=BF16, device=DEV)
+    k.skinny_gemm(X.to(DEV), _interleave_gate_up(G, U).to(DEV), C, ws, epilogue=k.SK_SWIGLU)
+    ref = torch.nn.functional.silu((X.float() @ G.float().t()).to(BF16)) * (X.float() @ U.float().t()).to(BF16)
+    _close(C, ref, ulps=3.0, what="skinny swiglu")
+
+
+@pytest.mark.parametrize("rows,H,split", [(5, 256, 3), (4098, 3584, 4096), (130, 896, 0)])
+def test_rmsnorm(rows, H, split):
+    k = _K()
+    x, w1, w2 = _rand((rows, H), 2.0, 20), _rand((H,), 0.1, 21) + 1, _rand((H,), 0.1, 22) + 1
+    w1, w2 = w1.to(BF16), w2.to(BF16)
+    out = torch.empty((rows, H), dtype=BF16, device=DEV)
+    k.rmsnorm(x.to(DEV), out, w1.to(DEV), w2.to(DEV), split, 1e-6)
+    ref = torch.cat([O.rms_norm(x[:split], w1, 1e-6), O.rms_norm(x[split:], w2, 1e-6)])
+    _close(out, ref, what="rmsnorm")
+
+
+@pytest.mark.parametrize("und_rounding", [False, True])
+def test_qk_norm_rope_kv(und_rounding):
+    k = _K()
+    M, Hq, Hkv, D, split, S = 70, 4, 2, 128, 64, 192
+    qkv = _rand((M, (Hq + 2 * Hkv) * D), 1.5, 30)
+    qn = [(_rand((D,), 0.1, 31 + i) + 1).to(BF16) for i in range(2)]
+    kn = [(_rand((D,), 0.1, 33 + i) + 1).to(BF16) for i in range(2)]
+    pos = torch.tensor([3, 1000, 77])
+    cos, sin = O.rotary_cos_sin(pos, D, 1e6, BF16)
+    row_cs = (torch.arange(M) % 3).to(torch.int32)
+    row_slot = torch.randperm(S, generator=torch.Generator().manual_seed(5))[:M].to(torch.int32)
+    Q = torch.empty((M, Hq, D), dtype=BF16, device=DEV)
+    Kws = torch.zeros((Hkv, S, D), dtype=BF16, device=DEV)
+    Vt = torch.zeros((Hkv, D, S), dtype=BF16, device=DEV)
+    k.qk_norm_rope_kv(qkv.to(DEV), M, Hq, Hkv, D, qn[0].to(DEV), qn[1].to(DEV), kn[0].to(DEV), kn[1].to(DEV), split,
+                      cos.to(DEV), sin.to(DEV), row_cs.to(DEV), row_slot.to(DEV), Q, Kws, Vt, S, 1e-6, und_rounding)
+    q = qkv[:, :Hq * D].view(M, Hq, D)
+    kk = qkv[:, Hq * D:(Hq + Hkv) * D].view(M, Hkv, D)
+    v = qkv[:, (Hq + Hkv) * D:].view(M, Hkv, D)
+    if not und_rounding:
+        q, kk = q.float(), kk.float()
+    qn_ = torch.cat([O.rms_norm(q[:split], qn[0], 1e-6), O.rms_norm(q[split:], qn[1], 1e-6)])
+    kn_ = torch.cat([O.rms_norm(kk[:split], kn[0], 1e-6), O.rms_norm(kk[split:], kn[1], 1e-6)])
+    qe, ke = O.apply_rope(qn_, kn_, cos[row_cs.long()], sin[row_cs.long()])
+    _close(Q, qe.to(BF16), what="q")
+    rs = row_slot.long()
+    _close(Kws.cpu()[:, rs, :].permute(1, 0, 2), ke.to(BF16), what="k scatter")
+    assert torch.equal(Vt.cpu()[:, :, rs].permute(2, 0, 1), v), "v transposed scatter"
+    untouched = torch.ones(S, dtype=torch.bool)
+    untouched[rs] = False
+    assert float(Kws.cpu()[:, untouched].abs().max()) == 0.0 and float(Vt.cpu()[:, :, untouched].abs().max()) == 0.0
+
+
+def _attention_case(q_lens, ctx_lens, Hq, Hkv, seed, spike=False):
+    """Build Q and a KV workspace with per-sample [context | queries] ranges and the tile table."""
+    k = _K()
+    D = 128
+    g = torch.Generator().manual_seed(seed)
+    M = sum(q_lens)
+    kv_lens = [a + b for a, b in zip(q_lens, ctx_lens)]
+    starts, s = [], 0
+    for n in kv_lens:
+        starts.append(s)
+        s += (n + 63) // 64 * 64
+    S = s
+    Q = torch.randn(M, Hq, D, generator=g).to(BF16) * 2
+    Kf = torch.randn(Hkv, S, D, generator=g).to(BF16) * 2
+    Vf = torch.randn(Hkv, S, D, generator=g).to(BF16)
+    if spike:  # one key much closer to one query: forces a late jump of the running maximum
+        Kf[:, starts[0] + kv_lens[0] - 3] = Q[5, 0] * 3
+    tiles, r0 = [], 0
+    for n, st, kl in zip(q_lens, starts, kv_lens):
+        for q0 in range(0, n, 128):
+            tiles.append((r0 + q0, min(128, n - q0), st, kl))
+        r0 += n
+    Od = torch.full((M, Hq, D), float("nan"), dtype=BF16, device=DEV)
+    k.varlen_attention(Q.to(DEV), Kf.to(DEV), Vf.permute(0, 2, 1).contiguous().to(DEV), Od,
+                       torch.tensor(tiles, dtype=torch.int32).to(DEV), len(tiles), Hq, Hkv, D, S)
+    kk = torch.cat([Kf[:, st:st + kl].permute(1, 0, 2) for st, kl in zip(starts, kv_lens)])
+    vv = torch.cat([Vf[:, st:st + kl].permute(1, 0, 2) for st, kl in zip(starts, kv_lens)])
+    ref = O.varlen_attention(Q, kk, vv, q_lens, kv_lens, causal=False)
+    return Od, ref
+
+
+@pytest.mark.parametrize("q_lens,ctx_lens,Hq,Hkv", [
+    ([128], [0], 2, 1), ([2], [62], 2, 1), ([66, 130], [7, 300], 4, 2), ([258], [34], 14, 2), ([1026], [4100], 7, 1)])
+def test_varlen_attention(q_lens, ctx_lens, Hq, Hkv):
+    got, ref = _attention_case(q_lens, ctx_lens, Hq, Hkv, seed=40)
+    assert not torch.isnan(got.float()).any()
+    _close(got, ref, ulps=2.0, what="attention")
+
+
+def test_varlen_attention_running_max_jump():
+    got, ref = _attention_case([130], [500], 2, 1, seed=41, spike=True)
+    _close(got, ref, ulps=2.0, what="attention spike")
+
+
+@pytest.mark.parametrize("renorm,use_img,rmin", [("global", True, 0.0), ("global", False, 0.0), ("channel", True, 0.0),
+                                                 ("text_channel", True, 0.3), ("text_channel", False, 0.0)])
+def test_cfg_euler(renorm, use_img, rmin):
+    k = _K()
+    rows, P = 1000, 64
+    vc, vx, vi = _rand((rows, P), 0.8, 50), _rand((rows, P), 0.8, 51), _rand((rows, P), 0.8, 52)
+    vx = (vc.float() + 0.05 * vx.float()).to(BF16)
+    x = _rand((rows, P), 1.0, 53, dtype=torch.float32)
+    dt = torch.tensor(0.0123456789)
+    s_img = 1.5 if use_img else 1.0
+    ref_v = O.cfg_combine(vc, vx, vi if use_img else None, 4.0, s_img, rmin, renorm)
+    ref_x = x - ref_v * dt
+    xd = x.to(DEV).clone()
+    xb = torch.empty((rows, P), dtype=BF16, device=DEV)
+    vo = torch.empty((rows, P), dtype=BF16, device=DEV)
+    ws = torch.empty(k.cfg_workspace_bytes(rows, P), dtype=torch.uint8, device=DEV)
+    k.cfg_euler_update(vc.to(DEV), vx.to(DEV), vi.to(DEV) if use_img else None, 4.0, s_img, renorm, rmin, float(dt),
+                       xd, xb, vo, ws)
+    mism = (vo.cpu() != ref_v).float().mean()
+    assert mism < 1e-3, f"{renorm}: {mism:.5f} of combined-velocity elements differ from the torch bf16 graph"
+    assert float((xd.cpu() - ref_x).abs().max()) < 1e-3
+    assert torch.equal(xb.cpu(), xd.cpu().to(BF16))
+
+
+def test_cfg_euler_no_cfg_and_errors():
+    k = _K()
+    rows, P = 64, 64
+    vc = _rand((rows, P), 0.8, 60)
+    x = _rand((rows, P), 1.0, 61, dtype=torch.float32)
+    xd = x.to(DEV).clone()
+    xb = torch.empty((rows, P), dtype=BF16, device=DEV)
+    vo = torch.empty((rows, P), dtype=BF16, device=DEV)
+    ws = torch.empty(k.cfg_workspace_bytes(rows, P), dtype=torch.uint8, device=DEV)
+    k.cfg_euler_update(vc.to(DEV), None, None, 1.0, 1.0, "global", 0.0, 0.25, xd, xb, vo, ws)
+    assert torch.equal(vo.cpu(), vc)
+    assert torch.equal(xd.cpu(), x - (vc.float() * 0.25).to(BF16).float())
+    with pytest.raises(NotImplementedError):
+        k.cfg_euler_update(vc.to(DEV), vc.to(DEV), None, 4.0, 1.0, "local", 0.0, 0.25, xd, xb, vo, ws)
+    with pytest.raises(RuntimeError):
+        k.cfg_euler_update(vc.to(DEV), None, None, 4.0, 1.0, "global", 0.0, 0.25, xd, xb, vo, ws)
+
+
+def test_timestep_embedding_and_embed_latent():
+    k = _K()
+    from bagel_amd.config import tiny_dims
+    from bagel_amd.weights import make_llm_state_dict
+    from bagel_amd.engine import MoTEngine, MoTWeights
+    d = tiny_dims(1)
+    sd = make_llm_state_dict(d, 0)
+    eng = MoTEngine(d, MoTWeights.from_state_dict(d, sd, DEV), DEV)
+    ts, _ = O.flow_timesteps(12, 3.0)
+    table = eng.timestep_table(ts)
+    ref = O.time_embedder(sd, ts, d.timestep_freq_dim)
+    _close(table, ref, what="t_emb")
+    sinus = torch.empty((ts.numel(), d.timestep_freq_dim), dtype=BF16, device=DEV)
+    k.timestep_sinusoid(ts.to(DEV), sinus)
+    _close(sinus, O.timestep_embedding(ts, d.timestep_freq_dim).to(BF16), ulps=1.0, what="sinusoid")
+
+
+def test_error_reporting():
+    k = _K()
+    A = torch.zeros((8, 32), dtype=BF16, device=DEV)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        k.gemm(A, A, torch.zeros((8, 8), dtype=BF16, device=DEV))
