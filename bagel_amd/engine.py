@@ -181,6 +181,9 @@ class MoTEngine:
         self.w = weights
         self.device = device
         self._buf: Dict[str, torch.Tensor] = {}
+        # when set to a list, every gen-expert gate+up GEMM launch is bracketed by HIP events on the launch
+        # stream and (start, end, algorithmic flops) is appended (used by bench.py for the roofline figure)
+        self.profile_events: Optional[list] = None
         self.kws = None
         self.vtws = None
 
@@ -290,7 +293,14 @@ class MoTEngine:
             self._und_rows(lambda r0, n: K.skinny_gemm(O[Mv + r0:Mv + r0 + n], lw.wo[1], X[Mv + r0:Mv + r0 + n], skw,
                                                        residual=X[Mv + r0:Mv + r0 + n], epilogue=K.SK_RESIDUAL), Mt)
             K.rmsnorm(X, Xn, lw.ln_post[0], lw.ln_post[1], Mv, eps)
-            K.gemm(Xn, lw.wgu[0], Hm, epilogue=K.EPI_SWIGLU, M=Mv)
+            if self.profile_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                K.gemm(Xn, lw.wgu[0], Hm, epilogue=K.EPI_SWIGLU, M=Mv)
+                e1.record()
+                self.profile_events.append((e0, e1, 2.0 * Mv * 2 * I * H))
+            else:
+                K.gemm(Xn, lw.wgu[0], Hm, epilogue=K.EPI_SWIGLU, M=Mv)
             self._und_rows(lambda r0, n: K.skinny_gemm(Xn[Mv + r0:Mv + r0 + n], lw.wgu[1], Hm[Mv + r0:Mv + r0 + n],
                                                        skw, epilogue=K.SK_SWIGLU), Mt)
             K.gemm(Hm, lw.wd[0], X, residual=X, epilogue=K.EPI_RESIDUAL, M=Mv)

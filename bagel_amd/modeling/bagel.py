@@ -14,6 +14,7 @@ import torch
 from .. import _lib as K
 from ..config import BagelDims
 from ..engine import GenUnit, MoTEngine, MoTWeights
+from ..parallel import exchange_velocities, plan_exchange, world_info
 
 BF16 = torch.bfloat16
 
@@ -246,9 +247,13 @@ class Bagel:
         max_steps: Optional[int] = None,
         trace: Optional[list] = None,
         teacher_x: Optional[Sequence[torch.Tensor]] = None,
+        group=None,
     ):
         """Bagel.generate_image (bagel.py:1237-1347).  Returns a tuple of per-image ``[Nv, 64]`` fp32 latents
-        (on the device).  ``enable_taylorseer`` changes results by design and is not offered here."""
+        (on the device).  ``enable_taylorseer`` changes results by design and is not offered here.
+        When torch.distributed is initialised with more than one rank, the (sample, branch) units of each
+        step are split over the ranks of ``group`` (bagel_amd/parallel.py); every rank must make the same call
+        and every rank returns the same latents."""
         if enable_taylorseer:
             raise NotImplementedError("TaylorSeer step skipping is an approximation and is not implemented")
         if cfg_renorm_type not in K.RENORM and cfg_text_scale > 1.0:
@@ -275,20 +280,29 @@ class Bagel:
                                         cfg_img_past_key_values, cpu(cfg_img_key_values_lens),
                                         cpu(cfg_img_packed_key_value_indexes))
 
-        plan_full = eng.build_plan(units, sample_nv, sample_row0)
-        eng.load_context(plan_full)
-        # steps outside cfg_interval run the cond branch only; its units are the first rows/slots of the full plan
-        plan_cond = eng.build_plan(units[:n_cond], sample_nv, sample_row0) if len(units) > n_cond else plan_full
-        plan_cond.S = plan_full.S  # same workspace, same strides; the cond units own its first slots
+        # split the units over the ranks (one process per GPU); world == 1 keeps everything local
+        rank, world = world_info(group)
+        n_br = 1 + int(use_text) + int(use_img)
+        ex_full = plan_exchange([u.sample for u in units], [u.branch for u in units], sample_nv, n_br, rank, world)
+        ex_cond = plan_exchange([u.sample for u in units[:n_cond]], [0] * n_cond, sample_nv, n_br, rank, world)
+        local_full = [units[i] for i in ex_full.local_units]
+        local_cond = [units[i] for i in ex_cond.local_units]   # a prefix of local_full: same key slots
+        plan_full = eng.build_plan(local_full, sample_nv, sample_row0) if local_full else None
+        plan_cond = eng.build_plan(local_cond, sample_nv, sample_row0) if local_cond else None
+        if plan_full is not None:
+            eng.load_context(plan_full)
+            if plan_cond is not None:
+                plan_cond.S = plan_full.S  # same workspace, same strides; the cond units own its first slots
         for u in units:
             u.ctx_k = u.ctx_v = None  # context now lives in the workspace
         eng.set_latent_position_ids(cpu(packed_vae_position_ids))
 
         # text rows: embed_tokens([soi, eoi]) per unit, constant over steps (bagel.py:1389-1391)
         ids = cpu(packed_text_ids).to(torch.int32)
-        nb = len(seqlens)
         text_emb = {}
-        for plan in {id(plan_full): plan_full, id(plan_cond): plan_cond}.values():
+        for plan in (plan_full, plan_cond):
+            if plan is None:
+                continue
             idx = torch.cat([ids[2 * u.sample:2 * u.sample + 2] for u in plan.units]).to(dev)
             te = torch.empty((plan.Mt, d.hidden_size), device=dev, dtype=BF16)
             K.gather_rows(eng.w.embed_tokens, idx, te, plan.Mt)
@@ -315,11 +329,13 @@ class Bagel:
                 K.cast_f32_bf16(x_t, x_bf16)
             active = t > cfg_interval[0] and t <= cfg_interval[1]
             ts_, is_ = (cfg_text_scale, cfg_img_scale) if active else (1.0, 1.0)
-            plan = plan_full if (active and use_text) else plan_cond
-            vout = eng.forward_gen(plan, x_bf16, temb_table[i], text_emb[id(plan)])
+            full = active and use_text
+            plan, ex = (plan_full, ex_full) if full else (plan_cond, ex_cond)
+            vloc = eng.forward_gen(plan, x_bf16, temb_table[i], text_emb[id(plan)]) if plan is not None else None
+            vout = exchange_velocities(vloc, ex, d.patch_latent_dim, dev, BF16, group)
             v_cond = vout[:Nv]
-            v_text = vout[Nv:2 * Nv] if (active and use_text) else None
-            v_img = vout[2 * Nv:3 * Nv] if (active and use_img) else None
+            v_text = vout[Nv:2 * Nv] if full else None
+            v_img = vout[2 * Nv:3 * Nv] if (full and use_img) else None
             if trace is not None:
                 rec = {"x_t": x_t.clone(), "v_cond": v_cond.clone()}
                 if v_text is not None:

@@ -1,0 +1,185 @@
+"""Benchmark of the image-generation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): BAGEL-7B-MoT dims, 1024x1024 text-to-image, num_timesteps=50
+(49 Euler steps), text + image CFG with cfg_interval (0.4, 1.0): 41 steps run three branches, 8 run one,
+131 LLM forwards per image; random-init weights and a synthetic 34-token context (no checkpoint or
+tokenizer exists offline).  One "step" of this benchmark = one complete ``Bagel.generate_image`` call for
+the whole batch (N images on N GPUs: weak scaling, three units per rank per CFG step).
+Inputs (weights, context KV, noise) are resident in HBM before the timed region.
+
+Prints ONE JSON line; see DESIGN.md for the meaning of ``roofline`` and ``cpu_baseline``.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak of MI355X
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is then INVALID)")
+    ap.add_argument("--resolution", type=int, default=1024)
+    ap.add_argument("--num-timesteps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def synthetic_context(dims, n_samples, ctx_len, device, seed):
+    """NaiveCache with ``ctx_len`` random context tokens per sample (post-norm keys have unit RMS)."""
+    from bagel_amd.modeling import NaiveCache
+    cache = NaiveCache(dims.num_layers)
+    if ctx_len == 0:
+        return cache
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    for l in range(dims.num_layers):
+        cache.key_cache[l] = torch.randn((n_samples * ctx_len, dims.num_kv_heads, dims.head_dim), device=device,
+                                         dtype=torch.bfloat16, generator=g)
+        cache.value_cache[l] = torch.randn((n_samples * ctx_len, dims.num_kv_heads, dims.head_dim), device=device,
+                                           dtype=torch.bfloat16, generator=g) * 0.5
+    return cache
+
+
+def cpu_baseline(dims_full, resolution, num_timesteps):
+    """The CPU checker (oracle/, a port of the reference's PyTorch path) timed on this host's cores on a
+    bounded sample: one three-branch CFG flow step at BAGEL-7B width, 2 of 28 layers, same resolution.
+    Scaled to images/sec by layers and by the 131/3 step-equivalents per image."""
+    import dataclasses
+    from bagel_amd.config import width7b_dims
+    from tests.helpers import OracleRun
+    from tests.scenarios import Scenario
+    layers = 2
+    sc = Scenario("cpu_baseline", width7b_dims(layers), [(resolution, resolution)], [32], None, [32],
+                  num_timesteps=num_timesteps)
+    run = OracleRun(sc)
+    x = run.gi["packed_init_noises"]
+    t0 = time.perf_counter()
+    run.step(0, x)
+    dt = time.perf_counter() - t0
+    forwards_per_image = 131 if num_timesteps == 50 else 3 * (num_timesteps - 1)
+    per_forward_full = dt / 3 * (dims_full.num_layers / layers)
+    return {"value": 1.0 / (per_forward_full * forwards_per_image), "unit": "images/sec",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/bagel_oracle.py, one 3-branch CFG flow step at 7B width, {layers} of "
+                      f"{dims_full.num_layers} layers, {resolution}x{resolution}: {dt:.2f} s; scaled by layers and "
+                      f"{forwards_per_image} forwards/image"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from bagel_amd.config import BAGEL_7B
+    from bagel_amd.engine import MoTWeights
+    from bagel_amd.modeling import Bagel
+    import dataclasses
+    dims = BAGEL_7B if args.layers is None else dataclasses.replace(BAGEL_7B, num_layers=args.layers)
+    weights = MoTWeights.random(dims, dev, seed=0, vocab_rows=1024)
+    model = Bagel(dims, device=dev, weights=weights)
+    new_token_ids = dict(bos_token_id=1, eos_token_id=2, start_of_image=3, end_of_image=4)
+
+    B = world                     # weak scaling: one image per GPU
+    res = args.resolution
+    ctx_len = 34                  # 32-token prompt + bos/eos
+    cond = synthetic_context(dims, B, ctx_len, dev, 1)
+    empty = synthetic_context(dims, B, 0, dev, 2)
+    torch.manual_seed(42)
+    gi = model.prepare_vae_latent([ctx_len] * B, [ctx_len] * B, [(res, res)] * B, new_token_ids)
+    gt = model.prepare_vae_latent_cfg([0] * B, [0] * B, [(res, res)] * B)
+    gm = model.prepare_vae_latent_cfg([ctx_len] * B, [ctx_len] * B, [(res, res)] * B)
+    gi["packed_init_noises"] = gi["packed_init_noises"].to(dev)
+
+    def one_image_batch():
+        return model.generate_image(
+            past_key_values=cond, num_timesteps=args.num_timesteps, timestep_shift=3.0, cfg_renorm_min=0.0,
+            cfg_renorm_type="global", cfg_interval=[0.4, 1.0], cfg_text_scale=4.0, cfg_text_past_key_values=empty,
+            cfg_text_packed_position_ids=gt["cfg_packed_position_ids"],
+            cfg_text_packed_query_indexes=gt["cfg_packed_query_indexes"],
+            cfg_text_key_values_lens=gt["cfg_key_values_lens"],
+            cfg_text_packed_key_value_indexes=gt["cfg_packed_key_value_indexes"],
+            cfg_img_scale=1.5, cfg_img_past_key_values=cond,
+            cfg_img_packed_position_ids=gm["cfg_packed_position_ids"],
+            cfg_img_packed_query_indexes=gm["cfg_packed_query_indexes"],
+            cfg_img_key_values_lens=gm["cfg_key_values_lens"],
+            cfg_img_packed_key_value_indexes=gm["cfg_packed_key_value_indexes"], **gi)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_image_batch()
+    barrier()
+    # per-launch timing of the dominant kernel with HIP events on the launch stream, during the timed region
+    model.engine.profile_events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_image_batch()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    events = model.engine.profile_events
+    model.engine.profile_events = None
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        n_euler = args.num_timesteps - 1
+        ms_per_image_batch = elapsed / args.steps * 1e3
+        out = {
+            "metric": "images/sec (node) 1024² T2I 50-step CFG; ms per flow step at 1/2/4/8 GPU",
+            "value": B * args.steps / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_image_batch, "ms_per_flow_step": ms_per_image_batch / n_euler,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"BAGEL-7B-MoT dims ({dims.num_layers} layers), {res}x{res} T2I, "
+                                   f"num_timesteps={args.num_timesteps}, cfg_text 4.0 + cfg_img 1.5, "
+                                   f"cfg_interval (0.4,1.0), global renorm, random-init weights, 34-token context; "
+                                   f"one step = one generate_image call (VAE decode not included yet)",
+                       "global_batch": B, "units_per_rank_per_cfg_step": 3, "parallelism": f"cfg-branch x batch over {world} GPU"},
+        }
+        if events:
+            ms = [a.elapsed_time(b) for a, b, _ in events]
+            flops = sum(f for _, _, f in events) / len(events)
+            avg = sum(ms) / len(ms)
+            ach = flops / (avg * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                               "kernel": "gemm_bf16_nt_kernel<EPI_SWIGLU> (gen-expert gate+up projection)",
+                               "launches_timed": len(ms), "avg_launch_ms": avg, "avg_flops_per_launch": flops}
+        if not args.no_cpu_baseline and args.layers is None:
+            out["cpu_baseline"] = cpu_baseline(dims, res, args.num_timesteps)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
