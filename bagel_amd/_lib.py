@@ -65,7 +65,7 @@ def lib() -> ctypes.CDLL:
                                "(the HIP extension is the only compute path; there is no fallback)")
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.bagel_last_error.restype = ctypes.c_char_p
-        for name in ("bagel_skinny_gemm_workspace_bytes", "bagel_cfg_workspace_bytes", "bagel_vae_workspace_bytes"):
+        for name in ("bagel_skinny_gemm_workspace_bytes", "bagel_cfg_workspace_bytes", "bagel_groupnorm_workspace_bytes"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = ctypes.c_long
     return _lib
@@ -94,20 +94,21 @@ L = ctypes.c_long
 I = ctypes.c_int
 F = ctypes.c_float
 
-EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2
+EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU, EPI_BIAS_RESIDUAL, EPI_F32_SCALED = 0, 1, 2, 3, 4
 SK_BIAS, SK_RESIDUAL, SK_SWIGLU, SK_BIAS_SILU = 0, 1, 2, 3
 RENORM = {"global": 0, "channel": 1, "text_channel": 2}
 
 
-def gemm(A, W, C, bias=None, residual=None, epilogue=EPI_BIAS, M=None):
+def gemm(A, W, C, bias=None, residual=None, epilogue=EPI_BIAS, M=None, alpha=1.0):
     """C[M,N] = epilogue(A[M,K] @ W[N,K]^T) (bf16 2-D tensors, rows may be strided)."""
     M = A.shape[0] if M is None else M
     N, K = W.shape
-    assert A.dtype == W.dtype == C.dtype == torch.bfloat16 and A.shape[1] == K
+    assert A.dtype == W.dtype == torch.bfloat16 and A.shape[1] == K
+    assert C.dtype == (torch.float32 if epilogue == EPI_F32_SCALED else torch.bfloat16)
     assert A.stride(1) == 1 and W.stride(1) == 1 and C.stride(1) == 1
     _check(lib().bagel_gemm_bf16(_p(A), L(A.stride(0)), _p(W), L(W.stride(0)), _p(C), L(C.stride(0)), I(M), I(N), I(K),
                                  _p(bias), _p(residual), L(residual.stride(0) if residual is not None else 0),
-                                 I(epilogue), _stream()), "bagel_gemm_bf16")
+                                 I(epilogue), F(alpha), _stream()), "bagel_gemm_bf16")
     return C
 
 
@@ -183,3 +184,47 @@ def cfg_euler_update(v_cond, v_text, v_img, cfg_text_scale, cfg_img_scale, renor
                                         _p(v_t_out), I(rows), I(P), _p(workspace),
                                         L(workspace.numel() * workspace.element_size()), _stream()),
            "bagel_cfg_euler_update")
+
+
+# ---- FLUX VAE decoder ---------------------------------------------------------------------------
+def conv3x3(x, Hin, Win, Cin, w, bias, out, zero_page, upsample=False, residual=None):
+    Cout = w.shape[0]
+    _check(lib().bagel_conv3x3_nhwc_bf16(_p(x), I(Hin), I(Win), I(Cin), I(1 if upsample else 0), _p(w), I(Cout), _p(bias),
+                                         _p(residual), _p(out), _p(zero_page), _stream()), "bagel_conv3x3_nhwc_bf16")
+    return out
+
+
+def groupnorm_workspace_bytes(C):
+    return lib().bagel_groupnorm_workspace_bytes(I(C))
+
+
+def groupnorm_swish(x, npix, C, gamma, beta, out, workspace, swish=True, eps=1e-6):
+    _check(lib().bagel_groupnorm_swish_nhwc_bf16(_p(x), L(npix), I(C), _p(gamma), _p(beta), F(eps), I(1 if swish else 0),
+                                                 _p(out), _p(workspace), L(workspace.numel() * workspace.element_size()),
+                                                 _stream()), "bagel_groupnorm_swish_nhwc_bf16")
+    return out
+
+
+def softmax_rows(scores, probs):
+    rows, n = scores.shape
+    _check(lib().bagel_softmax_rows_f32_bf16(_p(scores), L(scores.stride(0)), I(rows), I(n), _p(probs),
+                                             L(probs.stride(0)), _stream()), "bagel_softmax_rows_f32_bf16")
+    return probs
+
+
+def transpose(x, out):
+    R, C = x.shape
+    _check(lib().bagel_transpose_bf16(_p(x), I(R), I(C), _p(out), _stream()), "bagel_transpose_bf16")
+    return out
+
+
+def vae_latent_im2col(z, scale_factor, shift_factor, out):
+    _, Cz, H, W = z.shape
+    _check(lib().bagel_vae_latent_im2col_bf16(_p(z), I(Cz), I(H), I(W), F(scale_factor), F(shift_factor), _p(out),
+                                              I(out.shape[1]), _stream()), "bagel_vae_latent_im2col_bf16")
+    return out
+
+
+def nhwc_to_nchw(x, npix, Cpad, C, out):
+    _check(lib().bagel_nhwc_to_nchw_bf16(_p(x), L(npix), I(Cpad), I(C), _p(out), _stream()), "bagel_nhwc_to_nchw_bf16")
+    return out

@@ -1,0 +1,212 @@
+// The 128x128-class MFMA GEMM tile shared by the dense projection GEMM (gemm.hip) and the implicit-GEMM
+// 3x3 convolution of the VAE decoder (vae.hip).  See gemm.hip for the structure.
+#pragma once
+#include "common.h"
+
+enum { EPI_BIAS = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_BIAS_RESIDUAL = 3, EPI_F32_SCALED = 4 };
+enum { A_DENSE = 0, A_CONV3X3 = 1 };
+
+struct GemmParams {
+  const bf16* A; long lda;
+  const bf16* W; long ldw;
+  bf16* C; long ldc;
+  const bf16* bias;
+  const bf16* R; long ldr;
+  int M, N, K;
+  int tiles_m, tiles_n;
+  float alpha;                 // EPI_F32_SCALED: C (fp32) = alpha * acc
+  // A_CONV3X3: A is an NHWC image [Hin][Win][Cin]; row m of the GEMM is output pixel (m / Wout, m % Wout),
+  // K runs over (ky, kx, c); taps outside the (optionally 2x nearest-upsampled) image read `zeros`.
+  int Hout, Wout, Hin, Win, Cin, upsample;
+  const bf16* zeros;
+};
+
+constexpr int BK = 64;            // bf16 elements per K step (128-byte LDS rows)
+constexpr int ROW_BYTES = BK * 2;
+
+template <int BM, int BN, int WM, int WN, int EPI, int AMODE>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmParams p) {
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN;  // per-wave tile
+  constexpr int FM = TM / 16, FN = TN / 16;  // 16x16 fragments per wave
+  constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES;
+  constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+  constexpr int A_ITERS = BM / 8 / NW, W_ITERS = BN / 8 / NW;  // 1-KiB DMA pieces per wave per stage
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split over the waves");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+  // contiguous range of tiles, and walk tiles in bands of 8 M-tiles so a band's A rows and the
+  // W column panels stay in that XCD's L2.
+  const int nwg = p.tiles_m * p.tiles_n;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, loc = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  constexpr int GROUP_M = 8;
+  const int band = wg / (GROUP_M * p.tiles_n);
+  const int band_first = band * GROUP_M;
+  const int band_rows = min(p.tiles_m - band_first, GROUP_M);
+  const int in_band = wg - band * GROUP_M * p.tiles_n;
+  const int tile_m = band_first + in_band % band_rows;
+  const int tile_n = in_band / band_rows;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- staging addresses: lane -> (row within 8-row piece, swizzled source chunk)
+  const int piece_row = lane >> 3;
+  const int src_chunk = (lane & 7) ^ piece_row;
+  const bf16* a_src[A_ITERS];
+  const bf16* w_src[W_ITERS];
+  int a_oy[A_ITERS], a_ox[A_ITERS];
+#pragma unroll
+  for (int it = 0; it < A_ITERS; ++it) {
+    const int row = (it * NW + wave) * 8 + piece_row;
+    const int grow = min(m0 + row, p.M - 1);
+    if constexpr (AMODE == A_DENSE) {
+      a_src[it] = p.A + (long)grow * p.lda + src_chunk * 8;
+    } else {
+      a_oy[it] = grow / p.Wout;
+      a_ox[it] = grow - a_oy[it] * p.Wout;
+      a_src[it] = p.A + src_chunk * 8;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < W_ITERS; ++it) {
+    const int row = (it * NW + wave) * 8 + piece_row;
+    const int grow = min(n0 + row, p.N - 1);
+    w_src[it] = p.W + (long)grow * p.ldw + src_chunk * 8;
+  }
+
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * STAGE_BYTES;
+    const int koff = kt * BK;
+    int tap_dy = 0, tap_dx = 0, c0 = 0;
+    if constexpr (AMODE == A_CONV3X3) {
+      const int tap = koff / p.Cin;
+      c0 = koff - tap * p.Cin;
+      tap_dy = tap / 3 - 1;
+      tap_dx = tap - (tap / 3) * 3 - 1;
+    }
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) {
+      const bf16* src;
+      if constexpr (AMODE == A_DENSE) {
+        src = a_src[it] + koff;
+      } else {
+        int y = a_oy[it] + tap_dy, x = a_ox[it] + tap_dx;
+        const bool ok = y >= 0 && y < p.Hout && x >= 0 && x < p.Wout;
+        if (p.upsample) {
+          y >>= 1;
+          x >>= 1;
+        }
+        src = ok ? a_src[it] + ((long)y * p.Win + x) * p.Cin + c0 : p.zeros + src_chunk * 8;
+      }
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(base + (it * NW + wave) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < W_ITERS; ++it)
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(w_src[it] + koff),
+                                       LDS_PTR(base + A_BYTES + (it * NW + wave) * 1024), 16, 0, 0);
+  };
+
+  // ---- fragment read offsets (bytes within a tile image)
+  const int frow = lane & 15, fq = lane >> 4;
+  int a_off[2], w_off[2];  // per 32-deep k step; rows advance by 16*ROW_BYTES per fragment (row & 7 unchanged)
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int chunk = (kk * 4 + fq) ^ (frow & 7);
+    a_off[kk] = (wm * TM + frow) * ROW_BYTES + chunk * 16;
+    w_off[kk] = A_BYTES + (wn * TN + frow) * ROW_BYTES + chunk * 16;
+  }
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();  // waits this wave's DMA (vmcnt 0) then the barrier: tile kt is in LDS, tile kt-1 is consumed
+    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    const char* base = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[FM], wf[FN];
+#pragma unroll
+      for (int j = 0; j < FM; ++j) af[j] = *(const bf16x8*)(base + a_off[kk] + j * 16 * ROW_BYTES);
+#pragma unroll
+      for (int i = 0; i < FN; ++i) wf[i] = *(const bf16x8*)(base + w_off[kk] + i * 16 * ROW_BYTES);
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds features n..n+3 (n = ... + fq*4) of token row m (= ... + frow)
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m = m0 + wm * TM + j * 16 + frow;
+    if (m >= p.M) continue;
+    if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+      for (int i = 0; i < FN; i += 2) {
+        const int n = n0 + wn * TN + i * 16 + fq * 4;  // row of the interleaved weight
+        if (n >= p.N) continue;
+        const int f = (n0 + wn * TN + i * 16) / 2 + fq * 4;  // output feature
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g = round_bf16(acc[i][j][r]);
+          const float u = round_bf16(acc[i + 1][j][r]);
+          o[r] = (bf16)(round_bf16(silu_f32(g)) * u);
+        }
+        *(bf16x4*)(p.C + (long)m * p.ldc + f) = o;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int n = n0 + wn * TN + i * 16 + fq * 4;
+        if (n >= p.N) continue;
+        bf16x4 o;
+        if constexpr (EPI == EPI_F32_SCALED) {
+          f32x4 o32;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o32[r] = acc[i][j][r] * p.alpha;
+          *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = o32;
+          continue;
+        } else if constexpr (EPI == EPI_RESIDUAL) {
+          const bf16x4 r4 = *(const bf16x4*)(p.R + (long)m * p.ldr + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16)(round_bf16(acc[i][j][r]) + (float)r4[r]);
+        } else if constexpr (EPI == EPI_BIAS_RESIDUAL) {
+          const bf16x4 r4 = *(const bf16x4*)(p.R + (long)m * p.ldr + n);
+          const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16)(round_bf16(acc[i][j][r] + (float)b4[r]) + (float)r4[r]);
+        } else {
+          if (p.bias != nullptr) {
+            const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16)(acc[i][j][r] + (float)b4[r]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16)acc[i][j][r];
+          }
+        }
+        *(bf16x4*)(p.C + (long)m * p.ldc + n) = o;
+      }
+    }
+  }
+}
+

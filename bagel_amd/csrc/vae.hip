@@ -1,0 +1,275 @@
+// FLUX VAE decoder kernels (gfx950): implicit-GEMM 3x3 convolution on the MFMA units, GroupNorm + swish,
+// the single-head mid-block attention helpers, and the layout converters at both ends.
+//
+// Activations are NHWC bf16 ([H*W][C]), so a 1x1 convolution IS bagel_gemm_bf16 and a 3x3 convolution is
+// the same GEMM tile with K running over (ky, kx, c) and the A-operand rows gathered by the LDS-DMA's
+// per-lane source address (out-of-image taps point at a zero page).  Nearest-neighbour 2x upsampling
+// (Upsample.forward, autoencoder.py:116-119) is folded into that gather.  Rounding points follow what
+// bf16 autocast does to the reference's fp32 VAE: convolutions consume and produce bf16, GroupNorm and
+// swish run in fp32 on the bf16 input and are rounded once when the next convolution casts its input.
+#include "gemm_tile.h"
+
+// -------------------------------------------------------------------------------------------------
+// conv3x3, stride 1, padding 1, optional fused nearest-2x upsample of the input.
+// nn.Conv2d calls at autoencoder.py:76,78 (ResnetBlock), :114 (Upsample), :248 (conv_out).
+// W is pre-arranged [Cout][ky][kx][Cin]; Cin % 64 == 0.
+// -------------------------------------------------------------------------------------------------
+extern "C" int bagel_conv3x3_nhwc_bf16(const void* x, int Hin, int Win, int Cin, int upsample, const void* w, int Cout,
+                                       const void* bias, const void* residual, void* out, const void* zero_page,
+                                       void* stream) {
+  BAGEL_CHECK(x && w && bias && out && zero_page, "bagel_conv3x3_nhwc_bf16: null operand");
+  BAGEL_CHECK(Cin % 64 == 0 && Cout % 4 == 0, "bagel_conv3x3_nhwc_bf16: Cin=%d must be a multiple of 64, Cout=%d of 4", Cin, Cout);
+  BAGEL_CHECK(Hin > 0 && Win > 0, "bagel_conv3x3_nhwc_bf16: empty image");
+  GemmParams p;
+  p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.upsample = upsample ? 1 : 0;
+  p.Hout = upsample ? 2 * Hin : Hin;
+  p.Wout = upsample ? 2 * Win : Win;
+  p.A = (const bf16*)x; p.lda = Cin;
+  p.W = (const bf16*)w; p.ldw = 9L * Cin;
+  p.C = (bf16*)out; p.ldc = Cout;
+  p.bias = (const bf16*)bias;
+  p.R = (const bf16*)residual; p.ldr = Cout;
+  p.M = p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin;
+  p.alpha = 1.f;
+  p.zeros = (const bf16*)zero_page;
+  constexpr int BM = 128, BN = 128;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const size_t lds = 2 * (BM + BN) * ROW_BYTES;
+  const dim3 grid(p.tiles_m * p.tiles_n), block(256);
+  if (residual)
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, 2, 2, EPI_BIAS_RESIDUAL, A_CONV3X3>), grid, block, lds,
+                       (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, 2, 2, EPI_BIAS, A_CONV3X3>), grid, block, lds, (hipStream_t)stream, p);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// GroupNorm(32 groups, eps) [+ swish] on NHWC bf16.  nn.GroupNorm at autoencoder.py:43,75,77,247 and
+// swish (:34-35).  Statistics in fp32 per (group) over H*W*C/32 values; three passes:
+// partial sums per block -> per-group mean/rstd -> y = swish((x - mean) * rstd * gamma + beta) -> bf16.
+// -------------------------------------------------------------------------------------------------
+constexpr int GN_BLOCKS = 512;
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16* __restrict__ x, long npix, int C,
+                                                         float* __restrict__ part) {
+  // thread owns one 8-channel chunk; consecutive threads cover consecutive chunks of a pixel (coalesced)
+  const int cpr = C / 8;
+  const int chunk = threadIdx.x % cpr;
+  const int ppb = 256 / cpr;  // pixels per block-iteration
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+  for (long pix = (long)blockIdx.x * ppb + threadIdx.x / cpr; pix < npix; pix += (long)gridDim.x * ppb) {
+    const bf16x8 v = *(const bf16x8*)(x + pix * C + chunk * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float f = (float)v[e];
+      s[e] += f;
+      q[e] += f * f;
+    }
+  }
+  __shared__ float sh[256][17];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sh[threadIdx.x][e] = s[e];
+    sh[threadIdx.x][8 + e] = q[e];
+  }
+  __syncthreads();
+  // thread t < C sums channel t over the block's pixel lanes
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int pl = 0; pl < ppb; ++pl) {
+      a += sh[pl * cpr + c / 8][c % 8];
+      b += sh[pl * cpr + c / 8][8 + c % 8];
+    }
+    part[((long)blockIdx.x * C + c) * 2] = a;
+    part[((long)blockIdx.x * C + c) * 2 + 1] = b;
+  }
+}
+
+__global__ void gn_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long npix, float eps,
+                                   float* __restrict__ stats) {
+  const int g = threadIdx.x;  // 32 groups
+  if (g >= 32) return;
+  const int cpg = C / 32;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblocks; ++b)
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      s += part[((long)b * C + c) * 2];
+      q += part[((long)b * C + c) * 2 + 1];
+    }
+  const double n = (double)npix * cpg;
+  const double mean = s / n;
+  const double var = q / n - mean * mean;
+  stats[2 * g] = (float)mean;
+  stats[2 * g + 1] = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)eps));
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ x, long npix, int C,
+                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int swish, bf16* __restrict__ out) {
+  const int cpr = C / 8;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= npix * cpr) return;
+  const int chunk = idx % cpr;
+  const int cpg = C / 32;
+  const bf16x8 v = *(const bf16x8*)(x + idx * 8);
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = chunk * 8 + e;
+    const int g = c / cpg;
+    float y = ((float)v[e] - stats[2 * g]) * stats[2 * g + 1] * gamma[c] + beta[c];
+    if (swish) y = y / (1.0f + __expf(-y));
+    o[e] = (bf16)y;
+  }
+  *(bf16x8*)(out + idx * 8) = o;
+}
+
+extern "C" long bagel_groupnorm_workspace_bytes(int C) { return ((long)GN_BLOCKS * C * 2 + 64) * sizeof(float); }
+
+extern "C" int bagel_groupnorm_swish_nhwc_bf16(const void* x, long npix, int C, const void* gamma_f32,
+                                               const void* beta_f32, float eps, int swish, void* out, void* workspace,
+                                               long workspace_bytes, void* stream) {
+  BAGEL_CHECK(x && gamma_f32 && beta_f32 && out && workspace, "bagel_groupnorm_swish_nhwc_bf16: null operand");
+  BAGEL_CHECK(C % 32 == 0 && C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0, "bagel_groupnorm_swish_nhwc_bf16: C=%d not supported", C);
+  BAGEL_CHECK(workspace_bytes >= bagel_groupnorm_workspace_bytes(C), "bagel_groupnorm_swish_nhwc_bf16: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  float* stats = part + (long)GN_BLOCKS * C * 2;
+  const int ppb = 256 / (C / 8);
+  const int nblocks = (int)((npix + ppb - 1) / ppb < GN_BLOCKS ? (npix + ppb - 1) / ppb : GN_BLOCKS);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nblocks), dim3(256), 0, st, (const bf16*)x, npix, C, part);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(64), 0, st, part, nblocks, C, npix, eps, stats);
+  const long n = npix * (C / 8);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const bf16*)x, npix, C, stats,
+                     (const float*)gamma_f32, (const float*)beta_f32, swish, (bf16*)out);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Row softmax of fp32 scores -> bf16 probabilities (one block per row).  With bagel_gemm_bf16's fp32
+// scaled epilogue (S = Q.K^T / sqrt(C)) and a second GEMM (P.V) this is AttnBlock.attention
+// (autoencoder.py:50-62): single head, head dim = 512 channels, all H*W tokens.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, long lds_, int n,
+                                                           bf16* __restrict__ p, long ldp) {
+  const float* row = s + (long)blockIdx.x * lds_;
+  __shared__ float sh[8];
+  float m = -INFINITY;
+  for (int i = threadIdx.x * 4; i < n; i += 1024) {
+    const f32x4 v = *(const f32x4*)(row + i);
+    m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int i = threadIdx.x * 4; i < n; i += 1024) {
+    const f32x4 v = *(const f32x4*)(row + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sum += __expf(v[e] - m);
+  }
+  sum = wave_sum(sum);
+  if ((threadIdx.x & 63) == 0) sh[4 + (threadIdx.x >> 6)] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (sh[4] + sh[5] + sh[6] + sh[7]);
+  bf16* prow = p + (long)blockIdx.x * ldp;
+  for (int i = threadIdx.x * 4; i < n; i += 1024) {
+    const f32x4 v = *(const f32x4*)(row + i);
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (bf16)(__expf(v[e] - m) * inv);
+    *(bf16x4*)(prow + i) = o;
+  }
+}
+
+extern "C" int bagel_softmax_rows_f32_bf16(const void* scores, long lds_, int rows, int n, void* probs, long ldp,
+                                           void* stream) {
+  BAGEL_CHECK(scores && probs && rows > 0 && n > 0 && n % 4 == 0 && lds_ % 4 == 0 && ldp % 4 == 0,
+              "bagel_softmax_rows_f32_bf16: bad arguments");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const float*)scores, lds_, n,
+                     (bf16*)probs, ldp);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[c][r] = in[r][c]   (bf16, 64x64 tiles through LDS): V^T for the P.V GEMM of the mid-block attention
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restrict__ in, int R, int C,
+                                                             bf16* __restrict__ out) {
+  __shared__ bf16 tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i / 64, c = i % 64;
+    tile[r][c] = (r0 + r < R && c0 + c < C) ? in[(long)(r0 + r) * C + c0 + c] : (bf16)0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i / 64, r = i % 64;
+    if (r0 + r < R && c0 + c < C) out[(long)(c0 + c) * R + r0 + r] = tile[r][c];
+  }
+}
+
+extern "C" int bagel_transpose_bf16(const void* in, int R, int C, void* out, void* stream) {
+  BAGEL_CHECK(in && out && R > 0 && C > 0, "bagel_transpose_bf16: bad arguments");
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)in, R, C, (bf16*)out);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Decoder input: z (NCHW fp32, Cz channels) -> im2col rows [H*W][Kpad] bf16 of bf16(z / scale + shift)
+// with K ordered (ky, kx, c) and zero padding (AutoEncoder.decode, autoencoder.py:320-322, followed by
+// conv_in, :252).  Cz = 16 is too thin for the implicit-GEMM gather, so conv_in runs as a dense GEMM on
+// these rows.
+// -------------------------------------------------------------------------------------------------
+__global__ void latent_im2col_kernel(const float* __restrict__ z, int Cz, int H, int W, float inv_scale, float shift,
+                                     bf16* __restrict__ out, int Kpad) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)H * W * Kpad) return;
+  const int k = idx % Kpad;
+  const long pix = idx / Kpad;
+  float v = 0.f;
+  if (k < 9 * Cz) {
+    const int tap = k / Cz, c = k % Cz;
+    const int y = (int)(pix / W) + tap / 3 - 1, x = (int)(pix % W) + tap % 3 - 1;
+    if (y >= 0 && y < H && x >= 0 && x < W) v = z[((long)c * H + y) * W + x] * inv_scale + shift;
+  }
+  out[idx] = (bf16)v;
+}
+
+extern "C" int bagel_vae_latent_im2col_bf16(const void* z_nchw_f32, int Cz, int H, int W, float scale_factor,
+                                            float shift_factor, void* out, int Kpad, void* stream) {
+  BAGEL_CHECK(z_nchw_f32 && out && Kpad >= 9 * Cz && Kpad % 64 == 0, "bagel_vae_latent_im2col_bf16: bad arguments");
+  const long n = (long)H * W * Kpad;
+  hipLaunchKernelGGL(latent_im2col_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)z_nchw_f32, Cz, H, W, 1.0f / scale_factor, shift_factor, (bf16*)out, Kpad);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}
+
+// Decoder output: NHWC bf16 with Cpad channels -> NCHW bf16 with C channels
+__global__ void nhwc_to_nchw_kernel(const bf16* __restrict__ in, long npix, int Cpad, int C, bf16* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= npix * C) return;
+  const int c = idx / npix;
+  const long pix = idx % npix;
+  out[idx] = in[pix * Cpad + c];
+}
+
+extern "C" int bagel_nhwc_to_nchw_bf16(const void* in, long npix, int Cpad, int C, void* out, void* stream) {
+  BAGEL_CHECK(in && out && npix > 0 && C > 0 && C <= Cpad, "bagel_nhwc_to_nchw_bf16: bad arguments");
+  const long n = npix * C;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)in,
+                     npix, Cpad, C, (bf16*)out);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}

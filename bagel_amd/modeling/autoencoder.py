@@ -1,0 +1,165 @@
+"""``AutoEncoder.decode``: the FLUX VAE decoder (modeling/autoencoder.py:196-272, 320-322) on HIP kernels.
+
+Weights come from a state dict with the reference's parameter names (``decoder.*`` of ae.safetensors,
+fp32).  At load time convolution weights are rounded to bf16 (what bf16 autocast does on every call)
+and re-laid out ``[Cout][ky][kx][Cin]`` for the implicit-GEMM kernel; GroupNorm affines stay fp32.
+Activations are NHWC bf16 on the device.  ``encode`` is not part of the generation hot path.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from .. import _lib as K
+from ..config import VAEDims
+
+BF16 = torch.bfloat16
+
+
+class AutoEncoder:
+    def __init__(self, params: VAEDims, state_dict: Dict[str, torch.Tensor], device="cuda:0"):
+        K.lib()
+        self.params = params
+        self.device = torch.device(device)
+        self.scale_factor = params.scale_factor
+        self.shift_factor = params.shift_factor
+        self.w: Dict[str, torch.Tensor] = {}
+        dev = self.device
+        conv_names = {n[:-len(".weight")] for n, t in state_dict.items() if n.startswith("decoder.") and t.dim() == 4}
+        for name, t in state_dict.items():
+            if not name.startswith("decoder."):
+                continue
+            t = t.detach().float()
+            if t.dim() == 4:
+                cout, cin, kh, kw = t.shape
+                if name == "decoder.conv_in.weight":
+                    # dense GEMM on im2col rows: K = (ky, kx, c) zero-padded to a multiple of 64
+                    w = t.permute(0, 2, 3, 1).reshape(cout, kh * kw * cin)
+                    kpad = (w.shape[1] + 63) // 64 * 64
+                    wp = torch.zeros((cout, kpad))
+                    wp[:, :w.shape[1]] = w
+                    self.w[name] = wp.to(BF16).to(dev)
+                elif kh == 3:
+                    w = t.permute(0, 2, 3, 1).contiguous()      # [Cout][ky][kx][Cin]
+                    if cout % 4:
+                        w = torch.cat([w, torch.zeros((4 - cout % 4,) + tuple(w.shape[1:]))])
+                    self.w[name] = w.reshape(w.shape[0], -1).to(BF16).to(dev)
+                else:
+                    self.w[name] = t.reshape(cout, cin).to(BF16).contiguous().to(dev)
+            elif name.endswith(".bias") and name[:-len(".bias")] in conv_names:
+                b = t
+                if b.numel() % 4:
+                    b = torch.cat([b, torch.zeros(4 - b.numel() % 4)])
+                self.w[name] = b.to(BF16).to(dev)
+            else:
+                self.w[name] = t.to(dev)                         # GroupNorm affine, fp32
+        self.zero_page = torch.zeros(256, dtype=torch.uint8, device=dev)
+        self._buf: Dict[str, torch.Tensor] = {}
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def _get(self, name, shape, dtype=BF16):
+        n = 1
+        for s in shape:
+            n *= s
+        cur = self._buf.get(name)
+        if cur is None or cur.numel() < n or cur.dtype != dtype:
+            cur = torch.empty(n, device=self.device, dtype=dtype)
+            self._buf[name] = cur
+        return cur[:n].view(*shape)
+
+    # ---- blocks ---------------------------------------------------------------------------------
+    def _gn(self, x, npix, C, name, out, swish=True):
+        ws = self._get("gn_ws", (K.groupnorm_workspace_bytes(C),), torch.uint8)
+        return K.groupnorm_swish(x, npix, C, self.w[name + ".weight"], self.w[name + ".bias"], out, ws, swish=swish)
+
+    def _resblock(self, x, H, W, cin, cout, name, out_name):
+        """ResnetBlock.forward (autoencoder.py:82-95); x [H*W, cin] -> [H*W, cout]."""
+        npix = H * W
+        t = self._gn(x, npix, cin, name + ".norm1", self._get("t0", (npix, cin)))
+        h = K.conv3x3(t, H, W, cin, self.w[name + ".conv1.weight"], self.w[name + ".conv1.bias"],
+                      self._get("t1", (npix, cout)), self.zero_page)
+        t = self._gn(h, npix, cout, name + ".norm2", self._get("t0", (npix, cout)))
+        out = self._get(out_name, (npix, cout))
+        if cin == cout:
+            return K.conv3x3(t, H, W, cout, self.w[name + ".conv2.weight"], self.w[name + ".conv2.bias"], out,
+                             self.zero_page, residual=x)
+        h2 = K.conv3x3(t, H, W, cout, self.w[name + ".conv2.weight"], self.w[name + ".conv2.bias"],
+                       self._get("t1", (npix, cout)), self.zero_page)
+        # x' = nin_shortcut(x); out = x' + h   (1x1 convolution = dense GEMM on NHWC rows)
+        return K.gemm(x, self.w[name + ".nin_shortcut.weight"], out, bias=self.w[name + ".nin_shortcut.bias"],
+                      residual=h2, epilogue=K.EPI_BIAS_RESIDUAL)
+
+    def _attnblock(self, x, H, W, C, name, out_name):
+        """AttnBlock.forward (autoencoder.py:50-65): one head over H*W tokens, head dim C."""
+        n = H * W
+        if n % 64:
+            raise NotImplementedError(f"mid-block attention needs h*w % 64 == 0 (got {H}x{W} latent pixels)")
+        hn = self._gn(x, n, C, name + ".norm", self._get("t0", (n, C)), swish=False)
+        q = K.gemm(hn, self.w[name + ".q.weight"], self._get("aq", (n, C)), bias=self.w[name + ".q.bias"])
+        k = K.gemm(hn, self.w[name + ".k.weight"], self._get("ak", (n, C)), bias=self.w[name + ".k.bias"])
+        v = K.gemm(hn, self.w[name + ".v.weight"], self._get("av", (n, C)), bias=self.w[name + ".v.bias"])
+        vt = K.transpose(v, self._get("avt", (C, n)))
+        o = self._get("ao", (n, C))
+        # scores in row chunks so the fp32 score matrix stays bounded (n can be 16384)
+        chunk = min(n, 4096)
+        s = self._get("as", (chunk, n), torch.float32)
+        p = self._get("ap", (chunk, n))
+        for r0 in range(0, n, chunk):
+            m = min(chunk, n - r0)
+            K.gemm(q[r0:r0 + m], k, s[:m], epilogue=K.EPI_F32_SCALED, alpha=float(C) ** -0.5)
+            K.softmax_rows(s[:m], p[:m])
+            K.gemm(p[:m], vt, o[r0:r0 + m])
+        return K.gemm(o, self.w[name + ".proj_out.weight"], self._get(out_name, (n, C)),
+                      bias=self.w[name + ".proj_out.bias"], residual=x, epilogue=K.EPI_BIAS_RESIDUAL)
+
+    # ---- API --------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        """z [1, z_channels, h, w] (fp32) -> image [1, 3, 8h, 8w] (bf16), AutoEncoder.decode (autoencoder.py:320-322)."""
+        v = self.params
+        assert z.dim() == 4 and z.shape[0] == 1 and z.shape[1] == v.z_channels, "decode expects [1, z_channels, h, w]"
+        z = z.to(device=self.device, dtype=torch.float32).contiguous()
+        H, W = int(z.shape[2]), int(z.shape[3])
+        nres = len(v.ch_mult)
+        C = v.ch * v.ch_mult[nres - 1]
+        w_in = self.w["decoder.conv_in.weight"]
+        cols = K.vae_latent_im2col(z, v.scale_factor, v.shift_factor, self._get("im2col", (H * W, w_in.shape[1])))
+        cur, other = "xa", "xb"
+        h = K.gemm(cols, w_in, self._get(cur, (H * W, C)), bias=self.w["decoder.conv_in.bias"])
+
+        def step(fn, *args):
+            nonlocal cur, other, h
+            h = fn(h, *args, other)
+            cur, other = other, cur
+
+        step(self._resblock, H, W, C, C, "decoder.mid.block_1")
+        step(self._attnblock, H, W, C, "decoder.mid.attn_1")
+        step(self._resblock, H, W, C, C, "decoder.mid.block_2")
+        for lvl in reversed(range(nres)):
+            cout = v.ch * v.ch_mult[lvl]
+            for b in range(v.num_res_blocks + 1):
+                step(self._resblock, H, W, C, cout, f"decoder.up.{lvl}.block.{b}")
+                C = cout
+            if lvl != 0:
+                name = f"decoder.up.{lvl}.upsample.conv"
+                h = K.conv3x3(h, H, W, C, self.w[name + ".weight"], self.w[name + ".bias"],
+                              self._get(other, (4 * H * W, C)), self.zero_page, upsample=True)
+                cur, other = other, cur
+                H, W = 2 * H, 2 * W
+        npix = H * W
+        t = self._gn(h, npix, C, "decoder.norm_out", self._get("t0", (npix, C)))
+        w_out = self.w["decoder.conv_out.weight"]
+        o = K.conv3x3(t, H, W, C, w_out, self.w["decoder.conv_out.bias"], self._get("t1", (npix, w_out.shape[0])),
+                      self.zero_page)
+        img = torch.empty((1, v.out_ch, H, W), device=self.device, dtype=BF16)
+        K.nhwc_to_nchw(o, npix, w_out.shape[0], v.out_ch, img)
+        return img
+
+    def encode(self, x):
+        raise NotImplementedError("VAE encode belongs to context building, not to the generation hot path")

@@ -23,13 +23,15 @@ const char* bagel_last_error(void);
 #define BAGEL_EPI_RESIDUAL 1 /* C = bf16(bf16(acc) + R) */
 #define BAGEL_EPI_SWIGLU 2   /* C[:, f] = bf16(bf16(silu(bf16(gate_f))) * bf16(up_f)); W rows interleaved
                                 [16 gate rows | 16 up rows] per 16 features; C has N/2 columns */
+#define BAGEL_EPI_BIAS_RESIDUAL 3 /* C = bf16(bf16(acc + bias) + R) */
+#define BAGEL_EPI_F32_SCALED 4    /* C is fp32: C = alpha * acc */
 
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T), bf16 operands, fp32 accumulation on the MFMA units.
  * Replaces the nn.Linear calls of the generation expert: q/k/v_proj_moe_gen (qwen2_navit.py:541-547),
  * o_proj_moe_gen (:605), mlp_moe_gen gate/up/down (:833, modeling_qwen2.py:200-201), vae2llm and
  * llm2vae (bagel.py:1396,1425), and the residual adds (:818,836).  K % 64 == 0, N % 4 == 0. */
 int bagel_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
-                    const void* bias, const void* residual, long ldr, int epilogue, void* stream);
+                    const void* bias, const void* residual, long ldr, int epilogue, float alpha, void* stream);
 
 /* epilogues of bagel_skinny_gemm_bf16 */
 #define BAGEL_SK_BIAS 0
@@ -93,6 +95,38 @@ long bagel_cfg_workspace_bytes(int rows, int P);
 int bagel_cfg_euler_update(const void* v_cond, const void* v_text, const void* v_img, float cfg_text_scale,
                            float cfg_img_scale, int renorm_type, float renorm_min, float dt, void* x_t, void* x_bf16,
                            void* v_t_out, int rows, int P, void* workspace, long workspace_bytes, void* stream);
+
+/* ---- FLUX VAE decoder (modeling/autoencoder.py:196-272, 320-322); activations are NHWC bf16 ---- */
+
+/* 3x3 convolution, stride 1, padding 1, as an implicit GEMM on the MFMA units; `upsample` != 0 first
+ * applies nearest-neighbour 2x upsampling to x (Upsample.forward, autoencoder.py:116-119).
+ *   x [Hin][Win][Cin], w [Cout][3][3][Cin], bias [Cout], residual/out [Hout*Wout][Cout]
+ *   out = bf16(acc + bias), or bf16(bf16(acc + bias) + residual) when residual != NULL
+ *   zero_page: >= 128 zero bytes of device memory (source of the padding taps).
+ * Replaces nn.Conv2d at autoencoder.py:76,78,114,248 and the `x + h` of ResnetBlock (:95). */
+int bagel_conv3x3_nhwc_bf16(const void* x, int Hin, int Win, int Cin, int upsample, const void* w, int Cout,
+                            const void* bias, const void* residual, void* out, const void* zero_page, void* stream);
+
+/* GroupNorm(32, eps) with fp32 affine, optional swish, fp32 statistics, bf16 in/out.
+ * Replaces nn.GroupNorm + swish at autoencoder.py:84-89, 51, 269-270. */
+long bagel_groupnorm_workspace_bytes(int C);
+int bagel_groupnorm_swish_nhwc_bf16(const void* x, long npix, int C, const void* gamma_f32, const void* beta_f32,
+                                    float eps, int swish, void* out, void* workspace, long workspace_bytes,
+                                    void* stream);
+
+/* probs[r] = softmax(scores[r]) (fp32 in, bf16 out): the softmax of AttnBlock.attention (autoencoder.py:60). */
+int bagel_softmax_rows_f32_bf16(const void* scores, long lds, int rows, int n, void* probs, long ldp, void* stream);
+
+/* out[C][R] = in[R][C]^T (bf16). */
+int bagel_transpose_bf16(const void* in, int R, int C, void* out, void* stream);
+
+/* im2col rows [H*W][Kpad] of bf16(z / scale_factor + shift_factor) for conv_in (autoencoder.py:321,252);
+ * z is NCHW fp32, K order (ky, kx, c), zero padded to Kpad (multiple of 64). */
+int bagel_vae_latent_im2col_bf16(const void* z_nchw_f32, int Cz, int H, int W, float scale_factor, float shift_factor,
+                                 void* out, int Kpad, void* stream);
+
+/* NHWC bf16 (Cpad channels) -> NCHW bf16 (first C channels). */
+int bagel_nhwc_to_nchw_bf16(const void* in, long npix, int Cpad, int C, void* out, void* stream);
 
 #ifdef __cplusplus
 }
