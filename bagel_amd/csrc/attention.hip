@@ -23,10 +23,14 @@
 #include "common.h"
 
 struct AttnTile {
-  int q_row0;    // first query row (row index into Q / O)
-  int n_rows;    // valid rows in this tile (<= 128)
-  int kv_start;  // first key slot of the sample (multiple of 64)
-  int kv_len;    // number of valid keys
+  int q_row0;       // first query row (row index into Q / O)
+  int n_rows;       // valid rows in this tile (<= 128)
+  int kv_start;     // first key slot of the sample (multiple of 64)
+  int kv_len;       // number of valid keys
+  int causal_base;  // < 0: every row sees all kv_len keys; >= 0: row r of the tile sees keys < causal_base + r + 1
+                    // (bottom-right aligned causal mask of flash-attn >= 2.1: causal_base = context length +
+                    //  index of the tile's first row among the sample's new tokens)
+  int pad[3];
 };
 
 struct AttnParams {
@@ -119,7 +123,10 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int n_kt = (t.kv_len + KT - 1) / KT;
+  const bool causal = t.causal_base >= 0;
+  const int kv_len = causal ? min(t.kv_len, t.causal_base + t.n_rows) : t.kv_len;
+  const int row_limit = causal ? t.causal_base + wave * 32 + l31 + 1 : kv_len;  // keys this lane's row may see
+  const int n_kt = (kv_len + KT - 1) / KT;
   stage(0, 0);
   for (int kt = 0; kt < n_kt; ++kt) {
     __syncthreads();
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     }
     // scale, mask the tail keys of the last tile
     const int key0 = kt * KT;
-    const bool tail = key0 + KT > t.kv_len;
+    const bool tail = key0 + KT > (causal ? t.causal_base + wave * 32 + 1 : kv_len);  // wave-uniform
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
         float v = s[b][r] * p.scale_log2;
         if (tail) {
           const int key = key0 + 32 * b + (r & 3) + 4 * ((r >> 2) & 1) + 8 * h + 16 * (r >> 3);
-          v = key < t.kv_len ? v : -INFINITY;
+          v = key < row_limit ? v : -INFINITY;
         }
         s[b][r] = v;
       }
@@ -161,14 +168,16 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[b][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    // rows of a padded tile (row >= n_rows, causal) can be fully masked so far: keep exp2 arguments finite
+    const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
     m_run = m_new;
     float psum = 0.f;
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(s[b][r] - m_new);
+        const float e = __builtin_amdgcn_exp2f(s[b][r] - m_safe);
         s[b][r] = e;
         psum += e;
       }

@@ -228,8 +228,8 @@ class MoTEngine:
             row_slot[t0 + 1] = ks + u.ctx_len + n + 1
             kv_len = u.ctx_len + n + 2
             for q0 in range(0, n, 128):
-                tiles.append((r0 + q0, min(128, n - q0), ks, kv_len))
-            tiles.append((t0, 2, ks, kv_len))
+                tiles.append((r0 + q0, min(128, n - q0), ks, kv_len, -1, 0, 0, 0))
+            tiles.append((t0, 2, ks, kv_len, -1, 0, 0, 0))
         cos, sin = rope_table([u.rope_pos for u in units], d.head_dim, d.rope_theta, self.device)
         dev = self.device
         return GenPlan(units, nv, Mv, Mt, S, kv_start, vae_row0, row_cs.to(dev), row_slot.to(dev), src_row.to(dev),
@@ -311,6 +311,86 @@ class MoTEngine:
         K.rmsnorm(X, Xn, w.norm[0], w.norm[1], Mv, eps, rows=Mv)
         K.gemm(Xn, w.l2v_w, Vout, bias=w.l2v_b, M=Mv)
         return Vout
+
+    # ---- understanding-mode prefill (context KV build) ------------------------------------------
+    def _linear_und(self, x, w, out, bias=None, residual=None, kind="bias"):
+        """x [M, K] through one understanding-expert projection: weight-streaming path for M <= 64 rows,
+        MFMA tile GEMM otherwise."""
+        M = x.shape[0]
+        if M <= 64:
+            skw = self._get("skinny_ws", (16 * 64 * max(2 * self.dims.intermediate_size, self.dims.q_dim + 2 * self.dims.kv_dim),),
+                            dtype=torch.float32)
+            ep = {"bias": K.SK_BIAS, "residual": K.SK_RESIDUAL, "swiglu": K.SK_SWIGLU}[kind]
+            return K.skinny_gemm(x, w, out, skw, bias=bias, residual=residual, epilogue=ep)
+        ep = {"bias": K.EPI_BIAS, "residual": K.EPI_RESIDUAL, "swiglu": K.EPI_SWIGLU}[kind]
+        return K.gemm(x, w, out, bias=bias, residual=residual, epilogue=ep)
+
+    def prefill_und(self, emb: torch.Tensor, lens: Sequence[int], pos0: Sequence[int], ctx_lens: Sequence[int],
+                    ctx_k: Sequence[Optional[List[torch.Tensor]]], ctx_v: Sequence[Optional[List[torch.Tensor]]],
+                    is_causal: bool = True):
+        """Qwen2Model.forward_inference(mode="und", update_past_key_values=True) for packed text tokens
+        (qwen2_navit.py:1041-1115 via bagel.py:844-874): returns per layer the merged keys and values
+        ``[sum(ctx + new), Hkv, D]`` in sample order, i.e. the tensors NaiveCache holds afterwards.
+        Sample b contributes ``lens[b]`` new tokens at RoPE positions pos0[b].. after ``ctx_lens[b]``
+        context tokens.  The last layer's attention and MLP are skipped: only keys/values are kept."""
+        d, w = self.dims, self.w
+        H, I, Hq, Hkv, D = d.hidden_size, d.intermediate_size, d.num_heads, d.num_kv_heads, d.head_dim
+        M = int(sum(lens))
+        assert emb.shape[0] == M
+        kv_start, row0 = [], []
+        s = r = 0
+        for n, c in zip(lens, ctx_lens):
+            kv_start.append(s)
+            row0.append(r)
+            s += (c + n + 63) // 64 * 64
+            r += n
+        S = s
+        L = d.num_layers
+        kws = self._get("kws_und", (L, Hkv, S, D), zero=True)
+        vtws = self._get("vtws_und", (L, Hkv, D, S), zero=True)
+        kws.zero_()
+        vtws.zero_()
+        positions, row_slot, tiles = [], [], []
+        for b, (n, c) in enumerate(zip(lens, ctx_lens)):
+            ks = kv_start[b]
+            if c > 0:
+                for l in range(L):
+                    kws[l, :, ks:ks + c, :].copy_(ctx_k[b][l].permute(1, 0, 2))
+                    vtws[l, :, :, ks:ks + c].copy_(ctx_v[b][l].permute(1, 2, 0))
+            positions += list(range(pos0[b], pos0[b] + n))
+            row_slot += list(range(ks + c, ks + c + n))
+            for q0 in range(0, n, 128):
+                tiles.append((row0[b] + q0, min(128, n - q0), ks, c + n, (c + q0) if is_causal else -1, 0, 0, 0))
+        cos, sin = rope_table(positions, D, d.rope_theta, self.device)
+        row_cs = torch.arange(M, dtype=torch.int32, device=self.device)
+        row_slot = torch.tensor(row_slot, dtype=torch.int32, device=self.device)
+        tiles_t = torch.tensor(tiles, dtype=torch.int32, device=self.device)
+        qkv_dim = d.q_dim + 2 * d.kv_dim
+        X = self._get("uX", (M, H))
+        X.copy_(emb)
+        Xn = self._get("uXn", (M, H))
+        QKV = self._get("uQKV", (M, qkv_dim))
+        Q = self._get("uQ", (M, d.q_dim))
+        O = self._get("uO", (M, d.q_dim))
+        Hm = self._get("uHm", (M, I))
+        eps = d.rms_norm_eps
+        for l, lw in enumerate(w.layers):
+            K.rmsnorm(X, Xn, lw.ln_in[1], None, M, eps)
+            self._linear_und(Xn, lw.wqkv[1], QKV, bias=lw.bqkv[1])
+            K.qk_norm_rope_kv(QKV, M, Hq, Hkv, D, lw.qn[1], None, lw.kn[1], None, M, cos, sin, row_cs, row_slot, Q,
+                              kws[l], vtws[l], S, eps, und_rounding=True)
+            if l == L - 1:
+                break
+            K.varlen_attention(Q, kws[l], vtws[l], O, tiles_t, len(tiles), Hq, Hkv, D, S)
+            self._linear_und(O, lw.wo[1], X, residual=X, kind="residual")
+            K.rmsnorm(X, Xn, lw.ln_post[1], None, M, eps)
+            self._linear_und(Xn, lw.wgu[1], Hm, kind="swiglu")
+            self._linear_und(Hm, lw.wd[1], X, residual=X, kind="residual")
+        keys, values = [], []
+        for l in range(L):
+            keys.append(torch.cat([kws[l, :, ks:ks + c + n, :].permute(1, 0, 2) for ks, n, c in zip(kv_start, lens, ctx_lens)]).contiguous())
+            values.append(torch.cat([vtws[l, :, :, ks:ks + c + n].permute(2, 0, 1) for ks, n, c in zip(kv_start, lens, ctx_lens)]).contiguous())
+        return keys, values
 
     def set_latent_position_ids(self, pos_ids: torch.Tensor):
         self._pos_id = pos_ids.to(device=self.device, dtype=torch.int32)

@@ -94,6 +94,72 @@ class Bagel:
     # ------------------------------------------------------------------------------------------
     # host index builders (bit-for-bit the reference's lists, incl. the CPU RNG draw order)
     # ------------------------------------------------------------------------------------------
+    def prepare_prompts(self, curr_kvlens, curr_rope, prompts, tokenizer, new_token_ids):
+        """bagel.py:806-841."""
+        packed_text_ids, packed_text_position_ids, text_token_lens = [], [], []
+        packed_text_indexes, packed_key_value_indexes = [], []
+        curr = 0
+        newlens, new_rope = [], []
+        for prompt, curr_kvlen, curr_position_id in zip(prompts, curr_kvlens, curr_rope):
+            packed_key_value_indexes.extend(range(curr, curr + curr_kvlen))
+            curr += curr_kvlen
+            text_ids = tokenizer.encode(prompt)
+            text_ids = [new_token_ids["bos_token_id"]] + text_ids + [new_token_ids["eos_token_id"]]
+            text_token_lens.append(len(text_ids))
+            packed_text_ids.extend(text_ids)
+            packed_text_position_ids.extend(range(curr_position_id, curr_position_id + len(text_ids)))
+            packed_text_indexes.extend(range(curr, curr + len(text_ids)))
+            newlens.append(curr_kvlen + len(text_ids))
+            new_rope.append(curr_position_id + len(text_ids))
+            curr += len(text_ids)
+        device = self.device
+        generation_input = {
+            "text_token_lens": torch.tensor(text_token_lens, dtype=torch.int, device=device),
+            "packed_text_ids": torch.tensor(packed_text_ids, dtype=torch.long, device=device),
+            "packed_text_position_ids": torch.tensor(packed_text_position_ids, dtype=torch.long, device=device),
+            "packed_text_indexes": torch.tensor(packed_text_indexes, dtype=torch.long, device=device),
+            "packed_key_value_indexes": torch.tensor(packed_key_value_indexes, dtype=torch.long, device=device),
+            "key_values_lens": torch.tensor(curr_kvlens, dtype=torch.int, device=device),
+        }
+        return generation_input, newlens, new_rope
+
+    @torch.no_grad()
+    def forward_cache_update_text(self, past_key_values: NaiveCache, packed_text_ids, packed_text_position_ids,
+                                  text_token_lens, packed_text_indexes, packed_key_value_indexes, key_values_lens):
+        """bagel.py:844-874: causal understanding-mode prefill of packed prompts; returns the updated cache."""
+        cpu = lambda t: t.detach().cpu()  # noqa: E731
+        lens = [int(x) for x in cpu(text_token_lens).tolist()]
+        kvl = [int(x) for x in cpu(key_values_lens).tolist()]
+        pos = cpu(packed_text_position_ids).tolist()
+        qi, ki = cpu(packed_text_indexes).tolist(), cpu(packed_key_value_indexes).tolist()
+        pos0, ctx_k, ctx_v = [], [], []
+        q = c = tot = 0
+        L = self.dims.num_layers
+        for b, n in enumerate(lens):
+            if pos[q:q + n] != list(range(pos[q], pos[q] + n)):
+                raise NotImplementedError("text position ids must be consecutive within a prompt (bagel.py:823)")
+            if ki[c:c + kvl[b]] != list(range(tot, tot + kvl[b])) or qi[q:q + n] != list(range(tot + kvl[b], tot + kvl[b] + n)):
+                raise NotImplementedError("packed indexes are not the contiguous per-sample layout of prepare_prompts")
+            pos0.append(pos[q])
+            if kvl[b] > 0:
+                ctx_k.append([past_key_values.key_cache[l][c:c + kvl[b]].to(self.device, BF16) for l in range(L)])
+                ctx_v.append([past_key_values.value_cache[l][c:c + kvl[b]].to(self.device, BF16) for l in range(L)])
+            else:
+                ctx_k.append(None)
+                ctx_v.append(None)
+            q += n
+            c += kvl[b]
+            tot += kvl[b] + n
+        ids = cpu(packed_text_ids).to(torch.int32).to(self.device)
+        emb = torch.empty((sum(lens), self.dims.hidden_size), device=self.device, dtype=BF16)
+        K.gather_rows(self.engine.w.embed_tokens, ids, emb, sum(lens))
+        keys, values = self.engine.prefill_und(emb, lens, pos0, kvl, ctx_k, ctx_v, is_causal=True)
+        # like the reference, the given cache object is updated and returned (qwen2_navit.py:607-609)
+        for l in range(L):
+            past_key_values.key_cache[l] = keys[l]
+            past_key_values.value_cache[l] = values[l]
+        return past_key_values
+
     def prepare_vae_latent(self, curr_kvlens, curr_rope, image_sizes, new_token_ids):
         """bagel.py:1145-1201."""
         packed_text_ids, packed_text_indexes = [], []

@@ -68,9 +68,12 @@ int bagel_qk_norm_rope_kv_bf16(const void* qkv, long ld, int M, int Hq, int Hkv,
                                const void* sin_table, const void* row_cs, const void* row_slot, void* Q, void* K_ws,
                                void* Vt_ws, long S, float eps, int und_rounding, void* stream);
 
-/* Packed varlen GQA attention, non-causal: replaces flash_attn_varlen_func (qwen2_navit.py:590-599).
- *   tiles [n_tiles] of {int q_row0, n_rows (<=128), kv_start (multiple of 64), kv_len}
- * Every query row of a tile attends key slots [kv_start, kv_start + kv_len) of its kv head. */
+/* Packed varlen GQA attention: replaces flash_attn_varlen_func (qwen2_navit.py:590-599).
+ *   tiles [n_tiles] of 8 x int32 {q_row0, n_rows (<=128), kv_start (multiple of 64), kv_len, causal_base, 0, 0, 0}
+ * Every query row of a tile attends key slots [kv_start, kv_start + kv_len) of its kv head; with
+ * causal_base >= 0, row r of the tile only sees the first causal_base + r + 1 of them (the bottom-right
+ * aligned causal mask of flash-attn >= 2.1; causal_base = context length + index of the tile's first row
+ * among the sample's new tokens).  causal_base = -1 for the non-causal generation forward. */
 int bagel_varlen_attention_bf16(const void* Q, const void* K_ws, const void* Vt_ws, void* O, const void* tiles,
                                 int n_tiles, int Hq, int Hkv, int head_dim, long S, void* stream);
 

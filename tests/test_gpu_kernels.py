@@ -159,7 +159,7 @@ def test_qk_norm_rope_kv(und_rounding):
     assert float(Kws.cpu()[:, untouched].abs().max()) == 0.0 and float(Vt.cpu()[:, :, untouched].abs().max()) == 0.0
 
 
-def _attention_case(q_lens, ctx_lens, Hq, Hkv, seed, spike=False):
+def _attention_case(q_lens, ctx_lens, Hq, Hkv, seed, spike=False, causal=False):
     """Build Q and a KV workspace with per-sample [context | queries] ranges and the tile table."""
     k = _K()
     D = 128
@@ -179,14 +179,14 @@ def _attention_case(q_lens, ctx_lens, Hq, Hkv, seed, spike=False):
     tiles, r0 = [], 0
     for n, st, kl in zip(q_lens, starts, kv_lens):
         for q0 in range(0, n, 128):
-            tiles.append((r0 + q0, min(128, n - q0), st, kl))
+            tiles.append((r0 + q0, min(128, n - q0), st, kl, (kl - n + q0) if causal else -1, 0, 0, 0))
         r0 += n
     Od = torch.full((M, Hq, D), float("nan"), dtype=BF16, device=DEV)
     k.varlen_attention(Q.to(DEV), Kf.to(DEV), Vf.permute(0, 2, 1).contiguous().to(DEV), Od,
                        torch.tensor(tiles, dtype=torch.int32).to(DEV), len(tiles), Hq, Hkv, D, S)
     kk = torch.cat([Kf[:, st:st + kl].permute(1, 0, 2) for st, kl in zip(starts, kv_lens)])
     vv = torch.cat([Vf[:, st:st + kl].permute(1, 0, 2) for st, kl in zip(starts, kv_lens)])
-    ref = O.varlen_attention(Q, kk, vv, q_lens, kv_lens, causal=False)
+    ref = O.varlen_attention(Q, kk, vv, q_lens, kv_lens, causal=causal)
     return Od, ref
 
 
@@ -196,6 +196,13 @@ def test_varlen_attention(q_lens, ctx_lens, Hq, Hkv):
     got, ref = _attention_case(q_lens, ctx_lens, Hq, Hkv, seed=40)
     assert not torch.isnan(got.float()).any()
     _close(got, ref, ulps=2.0, what="attention")
+
+
+@pytest.mark.parametrize("q_lens,ctx_lens,Hq,Hkv", [([34], [0], 2, 1), ([5, 200], [0, 77], 4, 2), ([300], [130], 14, 2)])
+def test_varlen_attention_causal(q_lens, ctx_lens, Hq, Hkv):
+    got, ref = _attention_case(q_lens, ctx_lens, Hq, Hkv, seed=42, causal=True)
+    assert not torch.isnan(got.float()).any()
+    _close(got, ref, ulps=2.0, what="causal attention")
 
 
 def test_varlen_attention_running_max_jump():

@@ -95,3 +95,97 @@ def test_api_errors():
     bad["packed_vae_token_indexes"] = gi["packed_vae_token_indexes"].flip(0)
     with pytest.raises(NotImplementedError):
         model.generate_image(past_key_values=None, **bad)
+
+
+class _Tok:
+    """Stand-in tokenizer: a prompt is a string of space-separated token ids."""
+
+    def encode(self, text):
+        return [int(t) for t in text.split()]
+
+
+@pytest.mark.parametrize("name", ["tiny_t2i", "tiny_edit3", "tiny_batch2", "gqa7_t2i", "w7b_1024"])
+def test_text_prefill_matches_reference(name):
+    """Bagel.prepare_prompts + forward_cache_update_text (causal und-mode prefill on HIP kernels) against
+    the context keys/values the reference produced for the cond branch."""
+    from tests.gpu_common import gpu_model
+    from tests.scenarios import NEW_TOKEN_IDS
+    from bagel_amd.modeling import NaiveCache
+    sc = SCENARIOS[name]
+    g = load_golden(name)
+    from bagel_amd.weights import make_llm_state_dict
+    model = gpu_model(sc, make_llm_state_dict(sc.dims, seed=sc.weight_seed))
+    prompts = sc.prompts("cond")
+    n = len(prompts)
+    gi, newlens, newrope = model.prepare_prompts([0] * n, [0] * n, [" ".join(map(str, p)) for p in prompts], _Tok(),
+                                                 NEW_TOKEN_IDS)
+    assert newlens == [len(p) + 2 for p in prompts] and newrope == newlens
+    past = model.forward_cache_update_text(NaiveCache(sc.dims.num_layers), **gi)
+    last = sc.dims.num_layers - 1
+    for key, got in (("k0", past.key_cache[0]), ("v0", past.value_cache[0]),
+                     ("k_last", past.key_cache[last]), ("v_last", past.value_cache[last])):
+        ref = g["cond_ctx." + key]
+        assert got.shape == ref.shape
+        ma, cos = metrics(got, ref)
+        assert ma <= 0.03 * float(ref.float().abs().max()) and cos >= 0.999, (key, ma, cos)
+
+
+def test_prefill_with_existing_context_matches_checker():
+    """Second prompt appended to a non-empty context (causal mask offset by the context length)."""
+    from tests.gpu_common import gpu_model, to_gpu_cache
+    from tests.scenarios import NEW_TOKEN_IDS
+    from oracle import bagel_oracle as O
+    from bagel_amd.weights import make_llm_state_dict
+    sc = SCENARIOS["tiny_edit3"]
+    sd = make_llm_state_dict(sc.dims, seed=sc.weight_seed)
+    model = gpu_model(sc, sd)
+    p1, p2 = [list(range(10, 10 + 70))], [list(range(100, 100 + 150))]
+    with torch.no_grad():
+        ogi, l1, r1 = O.prepare_prompts([0], [0], p1, NEW_TOKEN_IDS)
+        opast = O.forward_cache_update_text(sd, sc.dims, O.Cache(sc.dims.num_layers), **ogi)
+        ogi2, l2, r2 = O.prepare_prompts(l1, r1, p2, NEW_TOKEN_IDS)
+        gpast = to_gpu_cache(opast, sc.dims.num_layers)
+        opast = O.forward_cache_update_text(sd, sc.dims, opast, **ogi2)
+    gi2, gl2, gr2 = model.prepare_prompts(l1, r1, [" ".join(map(str, p2[0]))], _Tok(), NEW_TOKEN_IDS)
+    assert (gl2, gr2) == (l2, r2)
+    gpast = model.forward_cache_update_text(gpast, **gi2)
+    for l in (0, sc.dims.num_layers - 1):
+        for got, ref in ((gpast.key_cache[l], opast.key_cache[l]), (gpast.value_cache[l], opast.value_cache[l])):
+            assert got.shape == ref.shape
+            ma, cos = metrics(got, ref)
+            assert ma <= 0.03 * float(ref.float().abs().max()) and cos >= 0.999, (l, ma, cos)
+
+
+def test_inferencer_text_to_image_end_to_end():
+    """InterleaveInferencer(text=...) -> PIL image, all on HIP kernels (prefill, denoise loop, VAE decode),
+    against the reference's final latent decoded by the CPU checker.  Bar: PSNR >= 40 dB."""
+    from bagel_amd.inferencer import InterleaveInferencer
+    from bagel_amd.modeling import AutoEncoder
+    from bagel_amd.config import VAEDims
+    from bagel_amd.weights import make_llm_state_dict, make_vae_decoder_state_dict
+    from tests.gpu_common import gpu_model
+    from tests.scenarios import NEW_TOKEN_IDS
+    from tests.test_oracle_vae import psnr
+    from oracle import bagel_oracle as O
+    import numpy as np
+    sc = SCENARIOS["tiny_t2i"]
+    g = load_golden("tiny_t2i")
+    model = gpu_model(sc, make_llm_state_dict(sc.dims, seed=sc.weight_seed))
+    vd = VAEDims()
+    vsd = make_vae_decoder_state_dict(vd, seed=0)
+    inf = InterleaveInferencer(model, AutoEncoder(vd, vsd, "cuda:0"), _Tok(), None, None, NEW_TOKEN_IDS)
+    torch.manual_seed(sc.noise_seed)
+    out = inf(text=" ".join(map(str, sc.prompts("cond")[0])), cfg_text_scale=sc.cfg_text_scale,
+              cfg_img_scale=sc.cfg_img_scale, cfg_interval=list(sc.cfg_interval), timestep_shift=sc.timestep_shift,
+              num_timesteps=sc.num_timesteps, cfg_renorm_min=sc.cfg_renorm_min, cfg_renorm_type=sc.cfg_renorm_type,
+              image_shapes=sc.images[0])
+    img = out["image"]
+    assert img is not None and img.size == (sc.images[0][1], sc.images[0][0]) and out["text"] is None
+    with torch.no_grad():
+        ref = O.vae_decode(vsd, vd, O.unpatchify_latent(sc.dims, g["final_latent"], sc.images[0]), bf16=True)
+    ref8 = O.to_uint8_image(ref.float()).numpy().astype(np.float32)
+    got8 = np.asarray(img).astype(np.float32)
+    mse = float(((ref8 - got8) ** 2).mean())
+    p = 10 * np.log10(255.0 ** 2 / max(mse, 1e-12))
+    print(f"end-to-end T2I image PSNR vs reference pipeline: {p:.1f} dB")
+    assert p >= 40.0
