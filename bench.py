@@ -6,7 +6,8 @@ Workload (BASELINE.json configs[1]): BAGEL-7B-MoT dims, 1024x1024 text-to-image,
 (49 Euler steps), text + image CFG with cfg_interval (0.4, 1.0): 41 steps run three branches, 8 run one,
 131 LLM forwards per image; random-init weights and a synthetic 34-token context (no checkpoint or
 tokenizer exists offline).  One "step" of this benchmark = one complete ``Bagel.generate_image`` call for
-the whole batch (N images on N GPUs: weak scaling, three units per rank per CFG step).
+the whole batch (N images on N GPUs: weak scaling, three units per rank per CFG step) followed by the FLUX
+VAE decode of every image to uint8.
 Inputs (weights, context KV, noise) are resident in HBM before the timed region.
 
 Prints ONE JSON line; see DESIGN.md for the meaning of ``roofline`` and ``cpu_baseline``.
@@ -126,6 +127,25 @@ def main():
             cfg_img_key_values_lens=gm["cfg_key_values_lens"],
             cfg_img_packed_key_value_indexes=gm["cfg_packed_key_value_indexes"], **gi)
 
+    # FLUX VAE decoder (random-init at the true FLUX dims); images are decoded by the rank that owns them
+    from bagel_amd.config import VAEDims
+    from bagel_amd.modeling import AutoEncoder
+    from bagel_amd.weights import make_vae_decoder_state_dict
+    vd = VAEDims()
+    ae = AutoEncoder(vd, make_vae_decoder_state_dict(vd, seed=0), dev)
+    p_, c_ = dims.latent_patch_size, dims.latent_channel
+    hh = ww = res // dims.latent_downsample
+
+    def decode(latent):
+        z = latent.reshape(1, hh, ww, p_, p_, c_)
+        z = torch.einsum("nhwpqc->nchpwq", z).reshape(1, c_, hh * p_, ww * p_)
+        img = ae.decode(z)
+        return ((img * 0.5 + 0.5).clamp(0, 1)[0].permute(1, 2, 0) * 255).to(torch.uint8)
+
+    def one_step():
+        latents = one_image_batch()
+        return [decode(latents[b]) for b in range(B) if b % world == rank]
+
     def barrier():
         if world > 1:
             import torch.distributed as dist
@@ -133,13 +153,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        one_image_batch()
+        one_step()
     barrier()
     # per-launch timing of the dominant kernel with HIP events on the launch stream, during the timed region
     model.engine.profile_events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one_image_batch()
+        one_step()
     barrier()
     elapsed = time.perf_counter() - t0
     events = model.engine.profile_events
@@ -161,7 +181,7 @@ def main():
             "config": {"workload": f"BAGEL-7B-MoT dims ({dims.num_layers} layers), {res}x{res} T2I, "
                                    f"num_timesteps={args.num_timesteps}, cfg_text 4.0 + cfg_img 1.5, "
                                    f"cfg_interval (0.4,1.0), global renorm, random-init weights, 34-token context; "
-                                   f"one step = one generate_image call (VAE decode not included yet)",
+                                   f"one step = one generate_image call for the batch + VAE decode to uint8 of every image",
                        "global_batch": B, "units_per_rank_per_cfg_step": 3, "parallelism": f"cfg-branch x batch over {world} GPU"},
         }
         if events:
