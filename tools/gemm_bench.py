@@ -1,0 +1,58 @@
+"""Micro-benchmark of bagel_gemm_bf16 tile variants on the generation expert's shapes (random operands).
+
+    python tools/gemm_bench.py [variant ...]      # variants are values of BAGEL_GEMM_VARIANT
+
+Variants are interleaved round-robin in one process and timed with HIP events on the launch stream.
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bagel_amd import _lib as K  # noqa: E402
+
+SHAPES = [  # name, M, N, K, epilogue
+    ("gate_up", 12288, 37888, 3584, K.EPI_SWIGLU),
+    ("down", 12288, 3584, 18944, K.EPI_RESIDUAL),
+    ("qkv", 12288, 4608, 3584, K.EPI_BIAS),
+    ("o_proj", 12288, 3584, 3584, K.EPI_RESIDUAL),
+    ("gate_up_1unit", 4096, 37888, 3584, K.EPI_SWIGLU),
+]
+
+
+def main():
+    variants = [int(v) for v in sys.argv[1:]] or [-1]
+    dev = "cuda:0"
+    lib = K.lib()
+    rounds = int(os.environ.get("ROUNDS", "5"))
+    for name, M, N, Kd, epi in SHAPES:
+        A = torch.randn((M, Kd), device=dev, dtype=torch.bfloat16)
+        W = torch.randn((N, Kd), device=dev, dtype=torch.bfloat16) * 0.02
+        C = torch.empty((M, N // 2 if epi == K.EPI_SWIGLU else N), device=dev, dtype=torch.bfloat16)
+        R = torch.randn_like(C) if epi == K.EPI_RESIDUAL else None
+        b = torch.randn((N,), device=dev, dtype=torch.bfloat16) if epi == K.EPI_BIAS else None
+        flops = 2.0 * M * N * Kd
+        times = {v: [] for v in variants}
+        for r in range(rounds + 1):
+            for v in variants:
+                lib.bagel_set_gemm_variant(v)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    K.gemm(A, W, C, bias=b, residual=R, epilogue=epi)
+                e1.record()
+                torch.cuda.synchronize()
+                if r > 0:
+                    times[v].append(e0.elapsed_time(e1) / 3)
+        for v in variants:
+            t = sorted(times[v])
+            med = t[len(t) // 2]
+            print(f"{name:14s} variant {v}: median {med:.3f} ms  {flops / med / 1e9:.0f} TFLOP/s   min {t[0]:.3f} ms {flops / t[0] / 1e9:.0f} TFLOP/s",
+                  flush=True)
+        del A, W, C, R, b
+    lib.bagel_set_gemm_variant(-1)
+
+
+if __name__ == "__main__":
+    main()
