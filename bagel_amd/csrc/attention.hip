@@ -47,7 +47,7 @@ struct AttnParams {
 constexpr int KT = 64;  // keys per tile
 
 template <int HD>
-__global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
   static_assert(HD == 128, "head_dim 128 only");
   constexpr int KS = HD / 16;        // k steps of the score product
   constexpr int DB = HD / 32;        // 32-wide d blocks of the output
@@ -129,6 +129,9 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
   const int n_kt = (kv_len + KT - 1) / KT;
   stage(0, 0);
   for (int kt = 0; kt < n_kt; ++kt) {
+    // The LDS-DMA of tile kt must have landed before the barrier publishes it: the compiler's barrier
+    // fence does not reliably wait for LDS-DMA, so the wait is explicit.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (kt + 1 < n_kt) stage(kt + 1, (kt + 1) & 1);
     const char* kb = smem + (kt & 1) * STAGE;
@@ -146,46 +149,47 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
         s[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[b], 0, 0, 0);
       }
     }
-    // scale, mask the tail keys of the last tile
+    // mask the tail keys of the last tile (raw scores; the softmax scale is folded into the exponent)
     const int key0 = kt * KT;
     const bool tail = key0 + KT > (causal ? t.causal_base + wave * 32 + 1 : kv_len);  // wave-uniform
+    if (tail) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = s[b][r] * p.scale_log2;
-        if (tail) {
+        for (int r = 0; r < 16; ++r) {
           const int key = key0 + 32 * b + (r & 3) + 4 * ((r >> 2) & 1) + 8 * h + 16 * (r >> 3);
-          v = key < row_limit ? v : -INFINITY;
+          s[b][r] = key < row_limit ? s[b][r] : -INFINITY;
         }
-        s[b][r] = v;
-      }
+    }
     // online softmax: this lane holds 32 of the row's 64 keys, lane^32 the other 32
-    float mx = s[0][0];
+    float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;  // scale > 0 commutes with max
+    // The accumulators are rescaled only when some row of this wave raises its running maximum
+    // (alpha == 1 exactly otherwise), which after the first few tiles is rare.
+    if (__any(mx > m_run)) {
+      const float m_new = fmaxf(m_run, mx);
+      // rows of a padded tile (row >= n_rows, causal) can be fully masked so far: keep exp2 arguments finite
+      const float alpha = __builtin_amdgcn_exp2f(m_run - (m_new == -INFINITY ? 0.f : m_new));
+      m_run = m_new;
+      l_run *= alpha;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[b][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    // rows of a padded tile (row >= n_rows, causal) can be fully masked so far: keep exp2 arguments finite
-    const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
-    m_run = m_new;
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+    }
+    const float neg_m = m_run == -INFINITY ? 0.f : -m_run;
     float psum = 0.f;
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(s[b][r] - m_safe);
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[b][r], p.scale_log2, neg_m));
         s[b][r] = e;
         psum += e;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+    l_run += psum;
 
     // O^T += Vt . P^T : 4 k steps of 16 keys
 #pragma unroll

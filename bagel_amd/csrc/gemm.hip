@@ -21,6 +21,8 @@
 //   EPI_BIAS_RESIDUAL  C = bf16(bf16(acc + bias) + R)         x + conv(x) in the VAE decoder
 //   EPI_F32_SCALED     C (fp32) = alpha * acc                 attention scores of the VAE mid block
 #include "gemm_tile.h"
+#include "gemm_pingpong.h"
+#include "gemm_pipelined.h"
 
 static int g_gemm_variant = -1;  // -1: choose by problem size
 
@@ -33,6 +35,35 @@ static int launch_gemm(GemmParams p, int epilogue, hipStream_t stream) {
 #define LAUNCH(EPI)                                                                              \
   do {                                                                                           \
     auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, EPI, A_DENSE>;                                        \
+    static bool configured = false;                                                              \
+    if (!configured) {                                                                           \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      configured = true;                                                                         \
+    }                                                                                            \
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, p);                                       \
+  } while (0)
+  switch (epilogue) {
+    case EPI_BIAS: LAUNCH(EPI_BIAS); break;
+    case EPI_RESIDUAL: LAUNCH(EPI_RESIDUAL); break;
+    case EPI_SWIGLU: LAUNCH(EPI_SWIGLU); break;
+    case EPI_BIAS_RESIDUAL: LAUNCH(EPI_BIAS_RESIDUAL); break;
+    case EPI_F32_SCALED: LAUNCH(EPI_F32_SCALED); break;
+    default: bagel_set_error("bagel_gemm_bf16: unknown epilogue %d", epilogue); return 1;
+  }
+#undef LAUNCH
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int FAMILY>
+static int launch_gemm256(GemmParams p, int epilogue, hipStream_t stream) {
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  const dim3 grid(p.tiles_m * p.tiles_n), block(512);
+  const size_t lds = 2 * (256 + 256) * ROW_BYTES;
+#define LAUNCH(EPI)                                                                              \
+  do {                                                                                           \
+    auto kern = FAMILY == 0 ? gemm256_pingpong_kernel<EPI> : gemm256_pipelined_kernel<EPI>;      \
     static bool configured = false;                                                              \
     if (!configured) {                                                                           \
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -76,12 +107,15 @@ extern "C" int bagel_gemm_bf16(const void* A, long lda, const void* W, long ldw,
   p.bias = (const bf16*)bias;
   p.R = (const bf16*)residual; p.ldr = ldr;
   p.M = M; p.N = N; p.K = K; p.alpha = alpha;
-  // 256x256 tiles (8 waves, one workgroup per CU) once they fill the chip; 128x128 tiles (4 waves, two
-  // workgroups per CU) for smaller problems.  Measured on the 7B shapes: 1.24 vs 1.10 PFLOP/s on gate+up.
+  // 256x256 software-pipelined tiles (8 waves, one workgroup per CU) once they fill the chip; 128x128 tiles
+  // (4 waves, two workgroups per CU) for smaller problems.  Measured on the 7B gate+up shape (random
+  // operands): 128x128 1.10, 256x256 one-barrier loop 1.25, ping-pong 1.29, software-pipelined 1.38 PFLOP/s.
   const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  const int variant = g_gemm_variant >= 0 ? g_gemm_variant : (tiles256 >= 256 ? 1 : 0);
+  const int variant = g_gemm_variant >= 0 ? g_gemm_variant : (tiles256 >= 256 ? 3 : 0);
   switch (variant) {
     case 1: return launch_gemm<256, 256, 2, 4>(p, epilogue, (hipStream_t)stream);
+    case 2: return launch_gemm256<0>(p, epilogue, (hipStream_t)stream);
+    case 3: return launch_gemm256<1>(p, epilogue, (hipStream_t)stream);
     default: return launch_gemm<128, 128, 2, 2>(p, epilogue, (hipStream_t)stream);
   }
 }

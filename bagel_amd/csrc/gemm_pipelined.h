@@ -1,0 +1,135 @@
+// 256x256x64 bf16 GEMM tile, software-pipelined: ONE barrier per K step, placed where it cannot starve the
+// matrix pipe.
+//
+// Eight waves (2 along M x 4 along N, wave tile 128 x 64).  A K step is four phases of 16 MFMAs
+// (phase = (m half, 32-deep k slice)); the fragments of phase p+1 are read from LDS while phase p's MFMAs
+// run (two register sets), so a wave never waits on LDS at a phase boundary.  Per K step kt:
+//
+//   phase 0: read frags(kt, ph1)      | DMA W pieces of tile kt+2 | MFMA ph0
+//   phase 1: read frags(kt, ph2)      |                           | MFMA ph1
+//   phase 2: read frags(kt, ph3)      |                           | MFMA ph2
+//            wait: LDS reads of tile kt done, my DMA pieces of tile kt+1 landed;  BARRIER
+//   phase 3: read frags(kt+1, ph0)    | DMA A pieces of tile kt+2 | MFMA ph3   (operands already in registers)
+//
+// The barrier publishes tile kt+1 (every wave waited for its own DMA pieces) and retires tile kt's buffer
+// (every wave waited for its own reads of it), so that buffer can take tile kt+2's DMA right away; those
+// loads then have a whole K step (~2000 cycles) to land before they are waited for.  Phase 3's MFMAs need
+// nothing that the barrier guards, so the matrix pipe has work the moment the barrier opens.
+#pragma once
+#include "gemm_tile.h"
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256, NW = 8, TM = 128, TN = 64, FM = 8, FN = 4;
+  constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES, STAGE_BYTES = A_BYTES + W_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  int tile_m, tile_n;
+  gemm_tile_of_block(p, blockIdx.x, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int piece_row = lane >> 3;
+  const int src_chunk = (lane & 7) ^ piece_row;
+  const bf16* a_src[4];
+  const bf16* w_src[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = (it * NW + wave) * 8 + piece_row;
+    a_src[it] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + src_chunk * 8;
+    w_src[it] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + src_chunk * 8;
+  }
+  auto stage_a = [&](int kt) {
+    char* base = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a_src[it] + kt * BK), LDS_PTR(base + (it * NW + wave) * 1024), 16, 0, 0);
+  };
+  auto stage_w = [&](int kt) {
+    char* base = smem + (kt & 1) * STAGE_BYTES + A_BYTES;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(w_src[it] + kt * BK), LDS_PTR(base + (it * NW + wave) * 1024), 16, 0, 0);
+  };
+
+  const int frow = lane & 15, fq = lane >> 4;
+  int a_off[2], w_off[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int chunk = (kk * 4 + fq) ^ (frow & 7);
+    a_off[kk] = (wr * TM + frow) * ROW_BYTES + chunk * 16;
+    w_off[kk] = A_BYTES + (wc * TN + frow) * ROW_BYTES + chunk * 16;
+  }
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 af[2][4], wf[2][FN];
+  auto read_a = [&](const char* base, int set, int mh, int kk) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) af[set][j] = *(const bf16x8*)(base + a_off[kk] + (mh * 64 + j * 16) * ROW_BYTES);
+  };
+  auto read_w = [&](const char* base, int kk) {
+#pragma unroll
+    for (int i = 0; i < FN; ++i) wf[kk][i] = *(const bf16x8*)(base + w_off[kk] + i * 16 * ROW_BYTES);
+  };
+  auto mma = [&](int set, int mh, int kk) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][mh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], af[set][j], acc[i][mh * 4 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  const int nk = p.K / BK;
+  // prologue: tiles 0 and 1 in flight, tile 0 published, phase-0 fragments of tile 0 in registers
+  stage_a(0);
+  stage_w(0);
+  if (nk > 1) {
+    stage_a(1);
+    stage_w(1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 8 pieces of tile 0; tile 1 stays in flight
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  read_a(smem, 0, 0, 0);
+  read_w(smem, 0);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* base = smem + (kt & 1) * STAGE_BYTES;
+    const char* next = smem + ((kt + 1) & 1) * STAGE_BYTES;
+    // phase 0: (mh 0, kk 0) from set 0; prefetch (mh 0, kk 1) into set 1
+    read_a(base, 1, 0, 1);
+    read_w(base, 1);
+    if (kt >= 1 && kt + 1 < nk) stage_w(kt + 1);  // its A pieces went out in the previous step's phase 3
+    mma(0, 0, 0);
+    // phase 1: (mh 0, kk 1) from set 1; prefetch (mh 1, kk 0) into set 0
+    read_a(base, 0, 1, 0);
+    mma(1, 0, 1);
+    // phase 2: (mh 1, kk 0) from set 0; prefetch (mh 1, kk 1) into set 1
+    read_a(base, 1, 1, 1);
+    mma(0, 1, 0);
+    // all my reads of this tile are issued: wait for them and for my DMA pieces of the next tile, then sync
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // phase 3: (mh 1, kk 1) from set 1; prefetch the next tile's phase 0; refill this tile's buffer
+    if (kt + 1 < nk) {
+      read_a(next, 0, 0, 0);
+      read_w(next, 0);
+      if (kt + 2 < nk) stage_a(kt + 2);
+    }
+    mma(1, 1, 1);
+  }
+
+  gemm_epilogue<EPI, FN, FM>(p, acc, m0 + wr * TM, n0 + wc * TN, lane);
+}

@@ -24,6 +24,87 @@ struct GemmParams {
 constexpr int BK = 64;            // bf16 elements per K step (128-byte LDS rows)
 constexpr int ROW_BYTES = BK * 2;
 
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so each XCD gets a contiguous
+// range of tiles, walked in bands of 8 M-tiles so a band's A rows and the W column panels stay in that
+// XCD's L2.  Bijective for any tile count.
+__device__ __forceinline__ void gemm_tile_of_block(const GemmParams& p, int block, int& tile_m, int& tile_n) {
+  const int nwg = p.tiles_m * p.tiles_n;
+  int wg = block;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, loc = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  constexpr int GROUP_M = 8;
+  const int band = wg / (GROUP_M * p.tiles_n);
+  const int band_first = band * GROUP_M;
+  const int band_rows = min(p.tiles_m - band_first, GROUP_M);
+  const int in_band = wg - band * GROUP_M * p.tiles_n;
+  tile_m = band_first + in_band % band_rows;
+  tile_n = in_band / band_rows;
+}
+
+// Epilogue shared by the tile kernels: this lane holds, for fragment (i, j), features
+// n_base + i*16 + fq*4 .. +3 of token row m_base + j*16 + frow  (fq = lane >> 4, frow = lane & 15).
+template <int EPI, int FN, int FM>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (&acc)[FN][FM], int m_base, int n_base,
+                                              int lane) {
+  const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m = m_base + j * 16 + frow;
+    if (m >= p.M) continue;
+    if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+      for (int i = 0; i < FN; i += 2) {
+        const int n = n_base + i * 16 + fq * 4;  // row of the interleaved weight
+        if (n >= p.N) continue;
+        const int f = (n_base + i * 16) / 2 + fq * 4;  // output feature
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g = round_bf16(acc[i][j][r]);
+          const float u = round_bf16(acc[i + 1][j][r]);
+          o[r] = (bf16)(round_bf16(silu_f32(g)) * u);
+        }
+        *(bf16x4*)(p.C + (long)m * p.ldc + f) = o;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int n = n_base + i * 16 + fq * 4;
+        if (n >= p.N) continue;
+        bf16x4 o;
+        if constexpr (EPI == EPI_F32_SCALED) {
+          f32x4 o32;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o32[r] = acc[i][j][r] * p.alpha;
+          *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = o32;
+          continue;
+        } else if constexpr (EPI == EPI_RESIDUAL) {
+          const bf16x4 r4 = *(const bf16x4*)(p.R + (long)m * p.ldr + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16)(round_bf16(acc[i][j][r]) + (float)r4[r]);
+        } else if constexpr (EPI == EPI_BIAS_RESIDUAL) {
+          const bf16x4 r4 = *(const bf16x4*)(p.R + (long)m * p.ldr + n);
+          const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16)(round_bf16(acc[i][j][r] + (float)b4[r]) + (float)r4[r]);
+        } else {
+          if (p.bias != nullptr) {
+            const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16)(acc[i][j][r] + (float)b4[r]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16)acc[i][j][r];
+          }
+        }
+        *(bf16x4*)(p.C + (long)m * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
 template <int BM, int BN, int WM, int WN, int EPI, int AMODE>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmParams p) {
   constexpr int NW = WM * WN;
@@ -36,22 +117,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmParams p)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
-  // contiguous range of tiles, and walk tiles in bands of 8 M-tiles so a band's A rows and the
-  // W column panels stay in that XCD's L2.
-  const int nwg = p.tiles_m * p.tiles_n;
-  int wg = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, loc = wg >> 3;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  constexpr int GROUP_M = 8;
-  const int band = wg / (GROUP_M * p.tiles_n);
-  const int band_first = band * GROUP_M;
-  const int band_rows = min(p.tiles_m - band_first, GROUP_M);
-  const int in_band = wg - band * GROUP_M * p.tiles_n;
-  const int tile_m = band_first + in_band % band_rows;
-  const int tile_n = in_band / band_rows;
+  int tile_m, tile_n;
+  gemm_tile_of_block(p, blockIdx.x, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int tid = threadIdx.x;
@@ -135,7 +202,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmParams p)
   const int nk = p.K / BK;
   stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();  // waits this wave's DMA (vmcnt 0) then the barrier: tile kt is in LDS, tile kt-1 is consumed
+    // tile kt's LDS-DMA must have landed before the barrier publishes it (explicit: the compiler's barrier
+    // fence does not reliably wait for LDS-DMA); the barrier also retires tile kt-1's buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
     const char* base = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
@@ -153,60 +223,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmParams p)
     }
   }
 
-  // ---- epilogue: lane holds features n..n+3 (n = ... + fq*4) of token row m (= ... + frow)
-#pragma unroll
-  for (int j = 0; j < FM; ++j) {
-    const int m = m0 + wm * TM + j * 16 + frow;
-    if (m >= p.M) continue;
-    if constexpr (EPI == EPI_SWIGLU) {
-#pragma unroll
-      for (int i = 0; i < FN; i += 2) {
-        const int n = n0 + wn * TN + i * 16 + fq * 4;  // row of the interleaved weight
-        if (n >= p.N) continue;
-        const int f = (n0 + wn * TN + i * 16) / 2 + fq * 4;  // output feature
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float g = round_bf16(acc[i][j][r]);
-          const float u = round_bf16(acc[i + 1][j][r]);
-          o[r] = (bf16)(round_bf16(silu_f32(g)) * u);
-        }
-        *(bf16x4*)(p.C + (long)m * p.ldc + f) = o;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        const int n = n0 + wn * TN + i * 16 + fq * 4;
-        if (n >= p.N) continue;
-        bf16x4 o;
-        if constexpr (EPI == EPI_F32_SCALED) {
-          f32x4 o32;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o32[r] = acc[i][j][r] * p.alpha;
-          *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = o32;
-          continue;
-        } else if constexpr (EPI == EPI_RESIDUAL) {
-          const bf16x4 r4 = *(const bf16x4*)(p.R + (long)m * p.ldr + n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16)(round_bf16(acc[i][j][r]) + (float)r4[r]);
-        } else if constexpr (EPI == EPI_BIAS_RESIDUAL) {
-          const bf16x4 r4 = *(const bf16x4*)(p.R + (long)m * p.ldr + n);
-          const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16)(round_bf16(acc[i][j][r] + (float)b4[r]) + (float)r4[r]);
-        } else {
-          if (p.bias != nullptr) {
-            const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (bf16)(acc[i][j][r] + (float)b4[r]);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (bf16)acc[i][j][r];
-          }
-        }
-        *(bf16x4*)(p.C + (long)m * p.ldc + n) = o;
-      }
-    }
-  }
+  gemm_epilogue<EPI, FN, FM>(p, acc, m0 + wm * TM, n0 + wn * TN, lane);
 }
 

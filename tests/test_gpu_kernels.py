@@ -274,3 +274,34 @@ def test_error_reporting():
     A = torch.zeros((8, 32), dtype=BF16, device=DEV)
     with pytest.raises(RuntimeError, match="multiple of 64"):
         k.gemm(A, A, torch.zeros((8, 8), dtype=BF16, device=DEV))
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K,epi", [(700, 512, 256, "bias"), (512, 768, 1024, "residual"), (300, 1024, 192, "swiglu"),
+                                       (4096, 4608, 3584, "bias"), (256, 256, 64, "bias"), (260, 256, 128, "residual")])
+def test_gemm_tile_variants(variant, M, N, K, epi):
+    """Every tile variant (128x128, 256x256, 256x256 ping-pong) must give the same answers, ragged M included."""
+    k = _K()
+    lib = k.lib()
+    A, W = _rand((M, K), 1.0, 70), _rand((N, K), 0.05, 71)
+    acc = A.float() @ W.float().t()
+    lib.bagel_set_gemm_variant(variant)
+    try:
+        if epi == "bias":
+            b = _rand((N,), 0.5, 72)
+            C = torch.full((M, N), float("nan"), dtype=BF16, device=DEV)
+            k.gemm(A.to(DEV), W.to(DEV), C, bias=b.to(DEV))
+            ref = (acc + b.float()).to(BF16)
+        elif epi == "residual":
+            R = _rand((M, N), 1.0, 73)
+            C = R.to(DEV).clone()
+            k.gemm(A.to(DEV), W.to(DEV), C, residual=C, epilogue=k.EPI_RESIDUAL)
+            ref = (acc.to(BF16).float() + R.float()).to(BF16)
+        else:
+            C = torch.full((M, N // 2), float("nan"), dtype=BF16, device=DEV)
+            k.gemm(A.to(DEV), W.to(DEV), C, epilogue=k.EPI_SWIGLU)
+            a3 = acc.view(M, N // 32, 2, 16)
+            ref = (torch.nn.functional.silu(a3[:, :, 0].to(BF16)) * a3[:, :, 1].to(BF16)).reshape(M, N // 2)
+    finally:
+        lib.bagel_set_gemm_variant(-1)
+    _close(C, ref, ulps=3.0, what=f"variant {variant} {epi}")

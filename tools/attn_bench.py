@@ -1,0 +1,48 @@
+"""Micro-benchmark of bagel_varlen_attention_bf16 on the generation shapes (random Q/K/V)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bagel_amd import _lib as K  # noqa: E402
+
+
+def case(name, units, nv, ctx, Hq=28, Hkv=4, D=128, iters=10):
+    dev = "cuda:0"
+    M = units * (nv + 2)
+    Mv = units * nv
+    tiles, s = [], 0
+    for u in range(units):
+        kv_len = ctx + nv + 2
+        for q0 in range(0, nv, 128):
+            tiles.append((u * nv + q0, min(128, nv - q0), s, kv_len, -1, 0, 0, 0))
+        tiles.append((Mv + 2 * u, 2, s, kv_len, -1, 0, 0, 0))
+        s += (kv_len + 63) // 64 * 64
+    S = s
+    Q = torch.randn((M, Hq, D), device=dev, dtype=torch.bfloat16) * 2
+    Kw = torch.randn((Hkv, S, D), device=dev, dtype=torch.bfloat16) * 2
+    Vt = torch.randn((Hkv, D, S), device=dev, dtype=torch.bfloat16)
+    O = torch.empty_like(Q)
+    t = torch.tensor(tiles, dtype=torch.int32, device=dev)
+    flops = 4.0 * Hq * D * units * (nv + 2) * (ctx + nv + 2)
+    for _ in range(2):
+        K.varlen_attention(Q, Kw, Vt, O, t, len(tiles), Hq, Hkv, D, S)
+    times = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        K.varlen_attention(Q, Kw, Vt, O, t, len(tiles), Hq, Hkv, D, S)
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1))
+    times.sort()
+    med = times[len(times) // 2]
+    print(f"{name:24s} median {med:.3f} ms  {flops / med / 1e9:.0f} TFLOP/s  (min {times[0]:.3f} ms)", flush=True)
+
+
+if __name__ == "__main__":
+    case("t2i 3 units ctx34", 3, 4096, 34)
+    case("t2i 1 unit ctx34", 1, 4096, 34)
+    case("edit 3 units ctx9034", 3, 4096, 9034)
+    case("edit 24 units ctx9034", 24, 4096, 9034, iters=3)
