@@ -48,10 +48,18 @@ constexpr int KT = 64;  // keys per tile
 
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
-  static_assert(HD == 128, "head_dim 128 only");
+  static_assert(HD == 128 || HD == 64, "head_dim 128 or 64");
   constexpr int KS = HD / 16;        // k steps of the score product
   constexpr int DB = HD / 32;        // 32-wide d blocks of the output
   constexpr int K_BYTES = KT * HD * 2, V_BYTES = HD * KT * 2, STAGE = K_BYTES + V_BYTES;
+  constexpr int K_ROW_BYTES = HD * 2;            // 256 B (16 chunks) or 128 B (8 chunks)
+  constexpr int K_RPP = 1024 / K_ROW_BYTES;      // K rows per 1-KiB DMA piece
+  constexpr int K_CH = K_ROW_BYTES / 16;         // 16-byte chunks per K row
+  constexpr int K_IT = KT / K_RPP / 4;           // K pieces per wave and tile
+  constexpr int V_IT = HD / 8 / 4;               // Vt pieces (8 rows of 128 B) per wave and tile
+  // chunk XOR of a tile row: 256-B rows spread 16 rows over the 16 slots of a bank row; 128-B rows put even and
+  // odd rows on different halves, so the XOR uses row >> 1
+  auto k_swz = [](int row) { return HD == 128 ? (row & 15) : ((row >> 1) & 7); };
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   // work order: (kv head, tile, query head within the group) with each XCD taking a contiguous range,
@@ -80,27 +88,29 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + 16 * ks);
 
-  // ---- staging: K tile = 64 rows x 256 B (4 rows per DMA piece), Vt tile = 128 rows x 128 B (8 rows per piece)
+  // ---- staging: K tile = 64 rows x HD*2 B, Vt tile = HD rows x 128 B, both in 1-KiB DMA pieces
   const bf16* kbase = p.K + ((long)kvh * p.S + t.kv_start) * HD;
   const bf16* vbase = p.Vt + (long)kvh * HD * p.S + t.kv_start;
-  const bf16* k_src[4];
-  const bf16* v_src[4];
+  const bf16* k_src[K_IT];
+  const bf16* v_src[V_IT];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int piece = it * 4 + wave;
-    const int krow = piece * 4 + (lane >> 4);
-    k_src[it] = kbase + (long)krow * HD + (((lane & 15) ^ (krow & 15)) * 8);
-    const int vrow = piece * 8 + (lane >> 3);
+  for (int it = 0; it < K_IT; ++it) {
+    const int krow = (it * 4 + wave) * K_RPP + lane / K_CH;
+    k_src[it] = kbase + (long)krow * HD + (((lane % K_CH) ^ k_swz(krow)) * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < V_IT; ++it) {
+    const int vrow = (it * 4 + wave) * 8 + (lane >> 3);
     v_src[it] = vbase + (long)vrow * p.S + (((lane & 7) ^ ((vrow >> 1) & 7)) * 8);
   }
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * STAGE;
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
+    for (int it = 0; it < K_IT; ++it)
       __builtin_amdgcn_global_load_lds(GLOBAL_PTR(k_src[it] + (long)kt * KT * HD),
                                        LDS_PTR(base + (it * 4 + wave) * 1024), 16, 0, 0);
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
+    for (int it = 0; it < V_IT; ++it)
       __builtin_amdgcn_global_load_lds(GLOBAL_PTR(v_src[it] + kt * KT),
                                        LDS_PTR(base + K_BYTES + (it * 4 + wave) * 1024), 16, 0, 0);
   };
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
   int k_off[2];  // per 32-key block; chunk XOR depends on ks
   k_off[0] = pi * (HD * 2);
   k_off[1] = (32 + pi) * (HD * 2);
-  const int k_sw = pi & 15;  // (row & 15) is the same for both blocks
+  const int k_sw = k_swz(pi);  // the same for both 32-key blocks
   // Vt: row d = db*32 + l31; swizzle ((row >> 1) & 7) is the same for every db (32 | row offset)
   const int v_row_off = l31 * (KT * 2);
   const int v_sw = (l31 >> 1) & 7;
@@ -230,7 +240,7 @@ extern "C" int bagel_varlen_attention_bf16(const void* Q, const void* K, const v
                                            const void* tiles, int n_tiles, int Hq, int Hkv, int head_dim,
                                            long S, void* stream) {
   BAGEL_CHECK(Q && K && Vt && O && tiles, "bagel_varlen_attention_bf16: null operand");
-  BAGEL_CHECK(head_dim == 128, "bagel_varlen_attention_bf16: head_dim %d not supported (128 only)", head_dim);
+  BAGEL_CHECK(head_dim == 128 || head_dim == 64, "bagel_varlen_attention_bf16: head_dim %d not supported (128 or 64)", head_dim);
   BAGEL_CHECK(n_tiles > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "bagel_varlen_attention_bf16: bad head counts");
   BAGEL_CHECK(S > 0 && S % 64 == 0, "bagel_varlen_attention_bf16: S=%ld must be a positive multiple of 64", S);
   BAGEL_CHECK(((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O | (uintptr_t)tiles) % 16 == 0,
@@ -239,14 +249,18 @@ extern "C" int bagel_varlen_attention_bf16(const void* Q, const void* K, const v
   p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.Vt = (const bf16*)Vt; p.O = (bf16*)O;
   p.tiles = (const AttnTile*)tiles; p.n_tiles = n_tiles; p.Hq = Hq; p.Hkv = Hkv; p.S = S;
   p.scale_log2 = 1.4426950408889634f / sqrtf((float)head_dim);
-  const size_t lds = 2 * (KT * 128 * 2 + 128 * KT * 2);
-  auto kern = attention_kernel<128>;
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    configured = true;
+  const size_t lds = 2 * (size_t)(KT * head_dim * 2 + head_dim * KT * 2);
+  if (head_dim == 128) {
+    auto kern = attention_kernel<128>;
+    static bool configured = false;
+    if (!configured) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_tiles * Hq), dim3(256), lds, (hipStream_t)stream, p);
+  } else {
+    hipLaunchKernelGGL(attention_kernel<64>, dim3(n_tiles * Hq), dim3(256), lds, (hipStream_t)stream, p);
   }
-  hipLaunchKernelGGL(kern, dim3(n_tiles * Hq), dim3(256), lds, (hipStream_t)stream, p);
   BAGEL_LAUNCH_CHECK();
   return 0;
 }

@@ -176,7 +176,7 @@ def rope_table(positions: Sequence[int], head_dim: int, theta: float, device):
 
 class MoTEngine:
     def __init__(self, dims: BagelDims, weights: MoTWeights, device):
-        assert dims.head_dim in (128,), "the attention kernel is built for head_dim 128"
+        assert dims.head_dim in (128, 64), "the attention kernel is built for head_dim 128 and 64"
         self.dims = dims
         self.w = weights
         self.device = device

@@ -159,10 +159,9 @@ def test_qk_norm_rope_kv(und_rounding):
     assert float(Kws.cpu()[:, untouched].abs().max()) == 0.0 and float(Vt.cpu()[:, :, untouched].abs().max()) == 0.0
 
 
-def _attention_case(q_lens, ctx_lens, Hq, Hkv, seed, spike=False, causal=False):
+def _attention_case(q_lens, ctx_lens, Hq, Hkv, seed, spike=False, causal=False, D=128):
     """Build Q and a KV workspace with per-sample [context | queries] ranges and the tile table."""
     k = _K()
-    D = 128
     g = torch.Generator().manual_seed(seed)
     M = sum(q_lens)
     kv_lens = [a + b for a, b in zip(q_lens, ctx_lens)]
@@ -203,6 +202,14 @@ def test_varlen_attention_causal(q_lens, ctx_lens, Hq, Hkv):
     got, ref = _attention_case(q_lens, ctx_lens, Hq, Hkv, seed=42, causal=True)
     assert not torch.isnan(got.float()).any()
     _close(got, ref, ulps=2.0, what="causal attention")
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("q_lens,ctx_lens,Hq,Hkv", [([258], [18], 14, 2), ([2, 70], [0, 129], 4, 2)])
+def test_varlen_attention_head_dim_64(q_lens, ctx_lens, Hq, Hkv, causal):
+    got, ref = _attention_case(q_lens, ctx_lens, Hq, Hkv, seed=43, causal=causal, D=64)
+    assert not torch.isnan(got.float()).any()
+    _close(got, ref, ulps=2.0, what="attention D=64")
 
 
 def test_varlen_attention_running_max_jump():

@@ -13,7 +13,7 @@ from tests.helpers import OracleRun, load_golden, have_golden, metrics, check_ve
 from tests.scenarios import SCENARIOS  # noqa: E402
 from tests.gpu_common import run_scenario_on_gpu  # noqa: E402
 
-HD128 = [n for n, s in SCENARIOS.items() if s.dims.head_dim == 128]
+HD128 = list(SCENARIOS)  # head_dim 128 and 64 (the 0.5B-shaped plumbing configuration)
 
 
 @pytest.mark.parametrize("name", HD128)
