@@ -170,6 +170,13 @@ def cast_f32_bf16(x, out):
     _check(lib().bagel_cast_f32_bf16(_p(x), _p(out), L(x.numel()), _stream()), "bagel_cast_f32_bf16")
 
 
+def argmax_rows(logits, out):
+    rows, n = logits.shape
+    _check(lib().bagel_argmax_rows_bf16(_p(logits), L(logits.stride(0)), I(rows), I(n), _p(out), _stream()),
+           "bagel_argmax_rows_bf16")
+    return out
+
+
 def cfg_workspace_bytes(rows, P):
     return lib().bagel_cfg_workspace_bytes(I(rows), I(P))
 

@@ -472,3 +472,46 @@ extern "C" int bagel_cfg_euler_update(const void* v_cond, const void* v_text, co
   BAGEL_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Greedy token choice: out[r] = index of the first maximum of logits[r] (torch.argmax, bagel.py:1580).
+// One block per row; ties resolve to the lowest index, NaNs are never selected over numbers.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const bf16* __restrict__ logits, long ld, int n,
+                                                          int* __restrict__ out) {
+  const bf16* row = logits + (long)blockIdx.x * ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = (float)row[i];
+    if (v > best || (v == best && i < bi)) {
+      best = v;
+      bi = i;
+    }
+  }
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      const float v = sv[threadIdx.x + o];
+      const int i = si[threadIdx.x + o];
+      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) {
+        sv[threadIdx.x] = v;
+        si[threadIdx.x] = i;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = si[0] == 0x7fffffff ? 0 : si[0];
+}
+
+extern "C" int bagel_argmax_rows_bf16(const void* logits, long ld, int rows, int n, void* out_i32, void* stream) {
+  BAGEL_CHECK(logits && out_i32 && rows > 0 && n > 0, "bagel_argmax_rows_bf16: bad arguments");
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, ld, n,
+                     (int*)out_i32);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}

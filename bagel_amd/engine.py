@@ -54,6 +54,7 @@ class MoTWeights:
         self.t0_w = self.t0_b = self.t2_w = self.t2_b = None
         self.v2l_w = self.v2l_b = self.l2v_w = self.l2v_b = None
         self.pos_embed = None
+        self.lm_head = None         # [vocab, H]; only text decoding needs it
 
     @classmethod
     def from_state_dict(cls, dims: BagelDims, sd: Dict[str, torch.Tensor], device) -> "MoTWeights":
@@ -87,6 +88,8 @@ class MoTWeights:
         self.v2l_w, self.v2l_b = g("vae2llm.weight"), g("vae2llm.bias")
         self.l2v_w, self.l2v_b = g("llm2vae.weight"), g("llm2vae.bias")
         self.pos_embed = g("latent_pos_embed.pos_embed")
+        if "language_model.lm_head.weight" in sd:
+            self.lm_head = g("language_model.lm_head.weight")
         return self
 
     @classmethod
@@ -391,6 +394,99 @@ class MoTEngine:
             keys.append(torch.cat([kws[l, :, ks:ks + c + n, :].permute(1, 0, 2) for ks, n, c in zip(kv_start, lens, ctx_lens)]).contiguous())
             values.append(torch.cat([vtws[l, :, :, ks:ks + c + n].permute(2, 0, 1) for ks, n, c in zip(kv_start, lens, ctx_lens)]).contiguous())
         return keys, values
+
+    # ---- autoregressive text decoding ---------------------------------------------------------
+    def decode_greedy(self, start_tokens: Sequence[int], pos0: Sequence[int], ctx_lens: Sequence[int],
+                      ctx_k, ctx_v, max_length: int, end_token_id: Optional[int] = None, sample_fn=None,
+                      logits_trace: Optional[list] = None) -> torch.Tensor:
+        """Bagel.generate_text (bagel.py:1526-1596): one token per sample per step through the understanding
+        expert, causal over [context | generated so far].
+
+        The reference re-merges the whole KV cache and rebuilds its index lists on the host for every token
+        (qwen2_navit.py:574-581, bagel.py:1551-1587).  Here the KV workspace is sized once for
+        context + max_length, each step's keys/values are written in place at slot context + step, every
+        index table of every step is built once up front, and the chosen token never leaves the device
+        between steps (argmax kernel -> embedding gather); the host only looks at the tokens every 16 steps
+        to honour ``end_token_id`` (batch-1 semantics of bagel.py:1592).
+        Returns the fed tokens ``[steps, B]`` (int64), starting with ``start_tokens``.
+        """
+        d, w = self.dims, self.w
+        assert w.lm_head is not None, "text decoding needs language_model.lm_head.weight"
+        H, I, Hq, Hkv, D, L = d.hidden_size, d.intermediate_size, d.num_heads, d.num_kv_heads, d.head_dim, d.num_layers
+        B = len(start_tokens)
+        dev = self.device
+        kv_start, s = [], 0
+        for c in ctx_lens:
+            kv_start.append(s)
+            s += (c + max_length + 63) // 64 * 64
+        S = s
+        kws = self._get("kws_dec", (L, Hkv, S, D), zero=True)
+        vtws = self._get("vtws_dec", (L, Hkv, D, S), zero=True)
+        kws.zero_()
+        vtws.zero_()
+        for b, c in enumerate(ctx_lens):
+            if c > 0:
+                for l in range(L):
+                    kws[l, :, kv_start[b]:kv_start[b] + c, :].copy_(ctx_k[b][l].permute(1, 0, 2))
+                    vtws[l, :, :, kv_start[b]:kv_start[b] + c].copy_(ctx_v[b][l].permute(1, 2, 0))
+        # per-step tables for all steps at once: RoPE rows, key slots, attention tiles (one query row each)
+        positions = [pos0[b] + t for t in range(max_length) for b in range(B)]
+        cos, sin = rope_table(positions, D, d.rope_theta, dev)
+        row_cs = torch.arange(max_length * B, dtype=torch.int32, device=dev).view(max_length, B)
+        row_slot = torch.tensor([[kv_start[b] + ctx_lens[b] + t for b in range(B)] for t in range(max_length)],
+                                dtype=torch.int32, device=dev)
+        tiles = torch.tensor([[(b, 1, kv_start[b], ctx_lens[b] + t + 1, -1, 0, 0, 0) for b in range(B)]
+                              for t in range(max_length)], dtype=torch.int32, device=dev)
+        seq = torch.zeros((max_length + 1, B), dtype=torch.int32, device=dev)
+        seq[0] = torch.tensor(list(start_tokens), dtype=torch.int32, device=dev)
+        qkv_dim = d.q_dim + 2 * d.kv_dim
+        X = self._get("dX", (B, H))
+        Xn = self._get("dXn", (B, H))
+        QKV = self._get("dQKV", (B, qkv_dim))
+        Q = self._get("dQ", (B, d.q_dim))
+        O = self._get("dO", (B, d.q_dim))
+        Hm = self._get("dHm", (B, I))
+        V = w.lm_head.shape[0]
+        logits = self._get("dlogits", (B, V))
+        assert 1 <= B <= 64, "decode_greedy handles 1..64 samples per call"
+        skw = self._get("skinny_ws_dec", (16 * B * max(2 * I, qkv_dim, V),), dtype=torch.float32)
+        eps = d.rms_norm_eps
+
+        def lin(x, wt, out, **kw):
+            return K.skinny_gemm(x, wt, out, skw, **kw)
+
+        steps_done = 0
+        for t in range(max_length):
+            K.gather_rows(w.embed_tokens, seq[t], X, B)
+            for l, lw in enumerate(w.layers):
+                K.rmsnorm(X, Xn, lw.ln_in[1], None, B, eps)
+                lin(Xn, lw.wqkv[1], QKV, bias=lw.bqkv[1])
+                K.qk_norm_rope_kv(QKV, B, Hq, Hkv, D, lw.qn[1], None, lw.kn[1], None, B, cos, sin, row_cs[t], row_slot[t],
+                                  Q, kws[l], vtws[l], S, eps, und_rounding=True)
+                K.varlen_attention(Q, kws[l], vtws[l], O, tiles[t], B, Hq, Hkv, D, S)
+                lin(O, lw.wo[1], X, residual=X, epilogue=K.SK_RESIDUAL)
+                K.rmsnorm(X, Xn, lw.ln_post[1], None, B, eps)
+                lin(Xn, lw.wgu[1], Hm, epilogue=K.SK_SWIGLU)
+                lin(Hm, lw.wd[1], X, residual=X, epilogue=K.SK_RESIDUAL)
+            K.rmsnorm(X, Xn, w.norm[1], None, B, eps)
+            lin(Xn, w.lm_head, logits)
+            if logits_trace is not None:
+                logits_trace.append(logits.clone())
+            if sample_fn is None:
+                K.argmax_rows(logits, seq[t + 1])
+            else:
+                seq[t + 1] = sample_fn(logits).to(torch.int32)
+            steps_done = t + 1
+            if end_token_id is not None and (t % 16 == 15 or t == max_length - 1):
+                hit = (seq[1:t + 2, 0] == end_token_id).nonzero()
+                if hit.numel() > 0:
+                    steps_done = int(hit[0]) + 1   # the step that produced the end token is the last one run
+                    break
+        if end_token_id is not None:
+            hit = (seq[1:steps_done + 1, 0] == end_token_id).nonzero()
+            if hit.numel() > 0:
+                steps_done = int(hit[0]) + 1
+        return seq[:steps_done].to(torch.long)
 
     def set_latent_position_ids(self, pos_ids: torch.Tensor):
         self._pos_id = pos_ids.to(device=self.device, dtype=torch.int32)

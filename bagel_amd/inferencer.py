@@ -3,8 +3,8 @@ HIP-backed ``Bagel`` and ``AutoEncoder``.  Same constructor, same method names, 
 
 Covered: text prompts -> image (``interleave_inference`` / ``__call__`` with ``text=...``), ``gen_image``,
 ``decode_image``, context bookkeeping with ``deepcopy`` snapshots for the CFG branches.
-Not covered yet (raise NotImplementedError): image inputs (VAE encode + SigLIP prefill) and text decoding
-(``gen_text``, think mode); they are context-building paths outside the denoise loop.
+``gen_text`` and the think modes (autoregressive decoding through the understanding expert) are covered too.
+Not covered yet (raise NotImplementedError): image inputs (VAE encode + SigLIP prefill).
 """
 from __future__ import annotations
 
@@ -15,6 +15,16 @@ import torch
 from PIL import Image
 
 from .modeling.bagel import NaiveCache
+
+
+# System prompts of the reference's think modes (inferencer.py:15-21)
+VLM_THINK_SYSTEM_PROMPT = '''You should first think about the reasoning process in the mind and then provide the user with the answer. 
+The reasoning process is enclosed within <think> </think> tags, i.e. <think> reasoning process here </think> answer here'''
+
+GEN_THINK_SYSTEM_PROMPT = '''You should first think about the planning process in the mind and then generate the image. 
+The planning process is enclosed within <think> </think> tags, i.e. <think> planning process here </think> <|vision_start|> image will be generated here <|vision_end|>
+
+When you want to generate an image, use the special tokens <|vision_start|> and <|vision_end|> to indicate where the image should be placed.'''
 
 
 class InterleaveInferencer:
@@ -89,8 +99,19 @@ class InterleaveInferencer:
         image = (image * 0.5 + 0.5).clamp(0, 1)[0].permute(1, 2, 0) * 255
         return Image.fromarray(image.to(torch.uint8).cpu().numpy())
 
+    @torch.no_grad()
     def gen_text(self, gen_context, max_length=500, do_sample=True, temperature=1.0, return_tokens=False):
-        raise NotImplementedError("autoregressive text decoding (inferencer.py:215-244) is not implemented")
+        """inferencer.py:215-244."""
+        gen_context = deepcopy(gen_context)
+        generation_input = self.model.prepare_start_tokens(gen_context["kv_lens"], gen_context["ropes"], self.new_token_ids)
+        unpacked_latent = self.model.generate_text(
+            past_key_values=gen_context["past_key_values"], max_length=max_length, do_sample=do_sample,
+            temperature=temperature, end_token_id=self.new_token_ids["eos_token_id"], **generation_input)
+        output = self.tokenizer.decode(unpacked_latent[:, 0])
+        output = output.split("<|im_end|>")[0].split("<|im_start|>")[1]
+        if return_tokens:
+            return output, unpacked_latent[:, 0].tolist()
+        return output
 
     @torch.no_grad()
     def interleave_inference(self, input_lists: List[Union[str, Image.Image]], think=False, understanding_output=False,
@@ -99,12 +120,14 @@ class InterleaveInferencer:
                              cfg_renorm_min=0.0, cfg_renorm_type="global", image_shapes=(1024, 1024),
                              enable_taylorseer=False):
         """inferencer.py:247-325 for text inputs and image output."""
-        if think or understanding_output:
-            raise NotImplementedError("think / understanding output need text decoding, which is not implemented")
         output_list = []
         gen_context = self.init_gen_context()
         cfg_text_context = deepcopy(gen_context)
         cfg_img_context = deepcopy(gen_context)
+        if think:
+            system_prompt = VLM_THINK_SYSTEM_PROMPT if understanding_output else GEN_THINK_SYSTEM_PROMPT
+            gen_context = self.update_context_text(system_prompt, gen_context)
+            cfg_img_context = self.update_context_text(system_prompt, cfg_img_context)
         for input_term in input_lists:
             if isinstance(input_term, str):
                 cfg_text_context = deepcopy(gen_context)
@@ -114,6 +137,15 @@ class InterleaveInferencer:
                 gen_context = self.update_context_image(input_term, gen_context)
             else:
                 raise ValueError(f"Unsupported input type: {type(input_term)}")
+        if understanding_output:
+            output_list.append(self.gen_text(gen_context, do_sample=do_sample, temperature=text_temperature,
+                                             max_length=max_think_token_n))
+            return output_list
+        if think:
+            gen_text = self.gen_text(gen_context, do_sample=do_sample, temperature=text_temperature,
+                                     max_length=max_think_token_n)
+            gen_context = self.update_context_text(gen_text, gen_context)
+            output_list.append(gen_text)
         img = self.gen_image(image_shapes, gen_context, cfg_text_precontext=cfg_text_context,
                              cfg_img_precontext=cfg_img_context, cfg_text_scale=cfg_text_scale,
                              cfg_img_scale=cfg_img_scale, cfg_interval=cfg_interval, timestep_shift=timestep_shift,

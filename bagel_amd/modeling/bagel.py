@@ -160,6 +160,56 @@ class Bagel:
             past_key_values.value_cache[l] = values[l]
         return past_key_values
 
+    def prepare_start_tokens(self, curr_kvlens, curr_rope, new_token_ids):
+        """bagel.py:1502-1523."""
+        packed_start_tokens, packed_key_value_indexes, packed_query_position_ids = [], [], []
+        curr = 0
+        for curr_kvlen, curr_position_id in zip(curr_kvlens, curr_rope):
+            packed_key_value_indexes.extend(range(curr, curr + curr_kvlen))
+            packed_start_tokens.append(new_token_ids["bos_token_id"])
+            packed_query_position_ids.append(curr_position_id)
+            curr += curr_kvlen
+        device = self.device
+        return {
+            "packed_start_tokens": torch.tensor(packed_start_tokens, dtype=torch.long, device=device),
+            "packed_query_position_ids": torch.tensor(packed_query_position_ids, dtype=torch.long, device=device),
+            "key_values_lens": torch.tensor(curr_kvlens, dtype=torch.int, device=device),
+            "packed_key_value_indexes": torch.tensor(packed_key_value_indexes, dtype=torch.long, device=device),
+        }
+
+    @torch.no_grad()
+    def generate_text(self, past_key_values: NaiveCache, packed_key_value_indexes, key_values_lens, packed_start_tokens,
+                      packed_query_position_ids, max_length: int, do_sample: bool = False, temperature: float = 1.0,
+                      end_token_id: int = None, logits_trace: Optional[list] = None):
+        """bagel.py:1526-1596.  Returns the fed tokens ``[steps, B]`` (the start token first).  Greedy decoding
+        (``do_sample=False``) is fully on HIP kernels; with ``do_sample=True`` the token is drawn with
+        torch.multinomial from softmax(logits / temperature), as the reference does (its draws depend on the
+        device RNG and are not reproducible across implementations either).  The given cache is not modified."""
+        cpu = lambda t: t.detach().cpu()  # noqa: E731
+        kvl = [int(x) for x in cpu(key_values_lens).tolist()]
+        ki = cpu(packed_key_value_indexes).tolist()
+        if ki != list(range(sum(kvl))):
+            raise NotImplementedError("packed_key_value_indexes is not the contiguous layout of prepare_start_tokens")
+        L = self.dims.num_layers
+        ctx_k, ctx_v = [], []
+        c = 0
+        for n in kvl:
+            if n > 0:
+                ctx_k.append([past_key_values.key_cache[l][c:c + n].to(self.device, BF16) for l in range(L)])
+                ctx_v.append([past_key_values.value_cache[l][c:c + n].to(self.device, BF16) for l in range(L)])
+            else:
+                ctx_k.append(None)
+                ctx_v.append(None)
+            c += n
+        sample_fn = None
+        if do_sample:
+            def sample_fn(logits):
+                probs = torch.softmax(logits.float() / temperature, dim=-1)
+                return torch.multinomial(probs, num_samples=1).squeeze(1)
+        return self.engine.decode_greedy(cpu(packed_start_tokens).tolist(), cpu(packed_query_position_ids).tolist(), kvl,
+                                         ctx_k, ctx_v, max_length, end_token_id=end_token_id, sample_fn=sample_fn,
+                                         logits_trace=logits_trace)
+
     def prepare_vae_latent(self, curr_kvlens, curr_rope, image_sizes, new_token_ids):
         """bagel.py:1145-1201."""
         packed_text_ids, packed_text_indexes = [], []

@@ -90,6 +90,9 @@ int bagel_timestep_sinusoid_bf16(const void* t, int n, int dim, void* out, void*
 
 int bagel_cast_f32_bf16(const void* x, void* out, long n, void* stream);
 
+/* out[r] = index of the first maximum of logits[r][0..n) (int32): torch.argmax at bagel.py:1580. */
+int bagel_argmax_rows_bf16(const void* logits, long ld, int rows, int n, void* out_i32, void* stream);
+
 /* CFG combine + renorm + Euler update: bagel.py:1466-1500 and :1339.
  *   renorm_type 0 "global", 1 "channel", 2 "text_channel"; v_* are [rows][P] bf16 (P == 64);
  *   x_t fp32 [rows][P] is updated in place: x_t -= bf16(v_t * dt); x_bf16 receives bf16(x_t);

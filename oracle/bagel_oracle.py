@@ -324,6 +324,57 @@ def forward_cache_update_text(p, dims, past, packed_text_ids, packed_text_positi
     return past
 
 
+def prepare_start_tokens(curr_kvlens, curr_rope, new_token_ids):
+    """Bagel.prepare_start_tokens, bagel.py:1502-1523."""
+    toks, kvidx, pos = [], [], []
+    curr = 0
+    for kvlen, rope in zip(curr_kvlens, curr_rope):
+        kvidx.extend(range(curr, curr + kvlen))
+        toks.append(new_token_ids["bos_token_id"])
+        pos.append(rope)
+        curr += kvlen
+    return {
+        "packed_start_tokens": torch.tensor(toks, dtype=torch.long),
+        "packed_query_position_ids": torch.tensor(pos, dtype=torch.long),
+        "key_values_lens": torch.tensor(curr_kvlens, dtype=torch.int),
+        "packed_key_value_indexes": torch.tensor(kvidx, dtype=torch.long),
+    }
+
+
+def generate_text(p, dims, past, packed_key_value_indexes, key_values_lens, packed_start_tokens,
+                  packed_query_position_ids, max_length, end_token_id=None, logits_trace=None):
+    """Bagel.generate_text with do_sample=False (greedy), bagel.py:1526-1596."""
+    step = 0
+    seq = []
+    curr = packed_start_tokens
+    while step < max_length:
+        seq.append(curr)
+        emb = p["language_model.model.embed_tokens.weight"][curr]
+        query_lens = torch.ones_like(curr)
+        q_idx = torch.cumsum(key_values_lens, dim=0) + torch.arange(0, len(key_values_lens), dtype=key_values_lens.dtype)
+        unp = list(packed_key_value_indexes.split(key_values_lens.tolist(), dim=0))
+        for i in range(len(unp)):
+            unp[i] = unp[i] + i
+        packed_key_value_indexes = torch.cat(unp, dim=0)
+        out, past = llm_forward_inference(p, dims, emb, query_lens, packed_query_position_ids, q_idx, past,
+                                          key_values_lens, packed_key_value_indexes, update_past_key_values=True,
+                                          is_causal=True, mode="und")
+        logits = linear(out, p["language_model.lm_head.weight"])
+        if logits_trace is not None:
+            logits_trace.append(logits)
+        curr = torch.argmax(logits, dim=-1)
+        unp = list(packed_key_value_indexes.split(key_values_lens.tolist(), dim=0))
+        for i in range(len(unp)):
+            unp[i] = torch.cat([unp[i], torch.tensor([unp[i][-1] + 1])], dim=0)
+        packed_key_value_indexes = torch.cat(unp, dim=0)
+        key_values_lens = key_values_lens + 1
+        packed_query_position_ids = packed_query_position_ids + 1
+        step += 1
+        if end_token_id is not None and curr[0] == end_token_id:
+            break
+    return torch.stack(seq, dim=0)
+
+
 def prepare_vae_latent(dims, curr_kvlens, curr_rope, image_sizes, new_token_ids):
     """Bagel.prepare_vae_latent, bagel.py:1145-1201 (one CPU randn per image, in order)."""
     text_ids, text_idx, vae_pos, vae_idx, noises = [], [], [], [], []

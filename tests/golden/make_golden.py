@@ -8,7 +8,8 @@ weights into the reference ``Bagel``, builds the three CFG contexts with the
 reference's ``prepare_prompts`` / ``forward_cache_update_text``, runs the
 reference's ``generate_image`` and records, per Euler step: the input ``x_t``,
 each branch's velocity before CFG, and the combined velocity; plus the final
-latent.  VAE scenarios record ``AutoEncoder.decode`` outputs.  The files written
+latent.  Text cases record ``generate_text`` (greedy) tokens and per-step logits.  VAE scenarios record
+``AutoEncoder.decode`` outputs.  The files written
 here (tests/golden/*.safetensors) are the only thing that travels to the GPU box.
 """
 from __future__ import annotations
@@ -27,7 +28,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 import ref_harness as rh  # noqa: E402
-from scenarios import SCENARIOS, NEW_TOKEN_IDS  # noqa: E402
+from scenarios import SCENARIOS, TEXT_CASES, NEW_TOKEN_IDS  # noqa: E402
 from bagel_amd.config import VAEDims  # noqa: E402
 from bagel_amd.weights import make_llm_state_dict, make_vae_decoder_state_dict  # noqa: E402
 
@@ -137,6 +138,30 @@ def run_llm_scenario(sc):
     print(f"[{sc.name}] wrote {len(out)} tensors in {time.time() - t0:.1f}s")
 
 
+def run_text_case(tc):
+    """Reference Bagel.generate_text, greedy: the fed tokens and the lm_head output of every step."""
+    t0 = time.time()
+    sd = make_llm_state_dict(tc.dims, seed=tc.weight_seed, include_lm_head=True)
+    model = rh.build_reference_model(tc.dims, sd)
+    from modeling.bagel.qwen2_navit import NaiveCache
+    tok = rh.StandInTokenizer()
+    logits = []
+    hook = model.language_model.lm_head.register_forward_hook(lambda m, i, o: logits.append(o.clone()))
+    with torch.no_grad(), rh.autocast():
+        past, kvlens, ropes = build_context(model, NaiveCache, tc.prompts(), len(tc.prompt), tok)
+        gi = model.prepare_start_tokens(kvlens, ropes, NEW_TOKEN_IDS)
+        start = {k: v.clone() for k, v in gi.items()}   # generate_text edits packed_key_value_indexes in place
+        tokens = model.generate_text(past_key_values=past, max_length=tc.max_length, do_sample=False, **gi)
+    hook.remove()
+    out = {"tokens": tokens.to(torch.int64).contiguous(), "logits": torch.stack(logits).float().contiguous()}
+    for k, v in start.items():
+        out[f"start.{k}"] = v.to(torch.int64).contiguous()
+    save_file(out, os.path.join(HERE, f"{tc.name}.safetensors"),
+              metadata={"source": "reference Bagel.generate_text (greedy) on CPU, bf16 weights + bf16 autocast, "
+                                  "SDPA stand-in for flash_attn"})
+    print(f"[{tc.name}] tokens {tokens.T.tolist()} in {time.time() - t0:.1f}s")
+
+
 VAE_CASES = {"vae_128": (16, 16), "vae_256": (32, 32), "vae_512x384": (64, 48)}
 
 
@@ -158,9 +183,11 @@ def run_vae(name, latent_hw):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(SCENARIOS) + list(VAE_CASES))
+    names = sys.argv[1:] or (list(SCENARIOS) + list(TEXT_CASES) + list(VAE_CASES))
     for nme in names:
         if nme in SCENARIOS:
             run_llm_scenario(SCENARIOS[nme])
+        elif nme in TEXT_CASES:
+            run_text_case(TEXT_CASES[nme])
         else:
             run_vae(nme, VAE_CASES[nme])

@@ -76,3 +76,23 @@ SCENARIOS = {s.name: s for s in [
                                        num_kv_heads=2, vocab_size=2048),
              [(256, 256)], [16], None, [16], num_timesteps=10, slow=True),
 ]}
+
+
+@dataclass
+class TextCase:
+    """Greedy autoregressive decoding after a prefilled prompt (Bagel.generate_text, bagel.py:1526-1596)."""
+    name: str
+    dims: BagelDims
+    prompt: List[int]              # prompt tokens per sample
+    max_length: int
+    weight_seed: int = 0
+
+    def prompts(self) -> List[List[int]]:
+        return [_prompt(n, 97 + b, self.dims.vocab_size) for b, n in enumerate(self.prompt)]
+
+
+TEXT_CASES = {c.name: c for c in [
+    TextCase("text_tiny_b1", tiny_dims(2), [7], 12),
+    TextCase("text_tiny_b2", tiny_dims(3), [12, 40], 10, weight_seed=3),
+    TextCase("text_gqa7", _small_gqa(), [33], 8, weight_seed=1),
+]}

@@ -1,0 +1,142 @@
+"""Greedy text decoding on the HIP path (Bagel.generate_text) against the reference's golden tokens/logits."""
+import pytest
+import torch
+
+from tests.helpers import load_golden, metrics
+from tests.scenarios import TEXT_CASES, NEW_TOKEN_IDS
+
+pytestmark = pytest.mark.gpu
+
+
+class _Tok:
+    def encode(self, text):
+        return [int(t) for t in text.split()]
+
+    def decode(self, ids):
+        return " ".join(str(int(i)) for i in ids)
+
+
+def _model(tc):
+    from bagel_amd.modeling import Bagel
+    from bagel_amd.weights import make_llm_state_dict
+    sd = make_llm_state_dict(tc.dims, seed=tc.weight_seed, include_lm_head=True)
+    return Bagel(tc.dims, state_dict=sd, device="cuda:0")
+
+
+def _context(model, tc):
+    from bagel_amd.modeling import NaiveCache
+    n = len(tc.prompt)
+    gi, kvlens, ropes = model.prepare_prompts([0] * n, [0] * n, [" ".join(map(str, p)) for p in tc.prompts()], _Tok(),
+                                              NEW_TOKEN_IDS)
+    past = model.forward_cache_update_text(NaiveCache(tc.dims.num_layers), **gi)
+    return past, kvlens, ropes
+
+
+def _logit_bound(ref):
+    return max(2e-2, 2.0 ** -6 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("name", list(TEXT_CASES))
+def test_generate_text_teacher_forced_logits(name):
+    """Feed the reference's tokens; every step's logits must match the reference's."""
+    tc = TEXT_CASES[name]
+    g = load_golden(name)
+    model = _model(tc)
+    past, kvlens, ropes = _context(model, tc)
+    gi = model.prepare_start_tokens(kvlens, ropes, NEW_TOKEN_IDS)
+    for k, v in gi.items():
+        assert torch.equal(v.cpu().to(torch.int64), g[f"start.{k}"]), k
+    ref_tokens = g["tokens"].to("cuda:0")
+    step = [0]
+
+    def forced(logits):
+        step[0] += 1
+        return ref_tokens[min(step[0], ref_tokens.shape[0] - 1)]
+
+    trace = []
+    model.engine.decode_greedy(gi["packed_start_tokens"].tolist(), gi["packed_query_position_ids"].tolist(),
+                               kvlens, *_split_ctx(model, past, kvlens), tc.max_length, sample_fn=forced,
+                               logits_trace=trace)
+    logits = torch.stack(trace).float().cpu()
+    ref = g["logits"]
+    assert logits.shape == ref.shape
+    ma, cos = metrics(logits, ref)
+    assert ma <= _logit_bound(ref) and cos >= 0.9999, (ma, cos)
+    # greedy choice on these logits: identical wherever the reference's top-2 margin exceeds the bound
+    top2 = ref.topk(2, dim=-1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 2 * _logit_bound(ref)
+    assert torch.equal(logits.argmax(-1)[clear], ref.argmax(-1)[clear])
+
+
+def _split_ctx(model, past, kvlens):
+    L = model.dims.num_layers
+    ks, vs, c = [], [], 0
+    for n in kvlens:
+        ks.append([past.key_cache[l][c:c + n] for l in range(L)])
+        vs.append([past.value_cache[l][c:c + n] for l in range(L)])
+        c += n
+    return ks, vs
+
+
+@pytest.mark.parametrize("name", list(TEXT_CASES))
+def test_generate_text_free_running(name):
+    """Bagel.generate_text end to end (device argmax feeds the next step).  Tokens must equal the reference's
+    up to the first step whose reference top-2 margin is within rounding noise."""
+    tc = TEXT_CASES[name]
+    g = load_golden(name)
+    model = _model(tc)
+    past, kvlens, ropes = _context(model, tc)
+    gi = model.prepare_start_tokens(kvlens, ropes, NEW_TOKEN_IDS)
+    k0 = past.key_cache[0].clone()
+    tokens = model.generate_text(past_key_values=past, max_length=tc.max_length, do_sample=False, **gi).cpu()
+    assert torch.equal(past.key_cache[0], k0)          # the caller's cache is left alone
+    ref = g["tokens"]
+    assert tokens.shape == ref.shape and tokens.dtype == torch.long
+    # identical tokens, except that a step whose two best reference logits are within rounding noise of
+    # each other may legitimately pick the other one; everything after such a step is a different sequence
+    for t in range(ref.shape[0] - 1):
+        if torch.equal(tokens[t + 1], ref[t + 1]):
+            continue
+        for b in range(ref.shape[1]):
+            lg = g["logits"][t, b]
+            assert float(lg[ref[t + 1, b]] - lg[tokens[t + 1, b]]) <= 2 * _logit_bound(g["logits"]), (t, b, tokens.T.tolist())
+        break
+
+
+def test_generate_text_end_token_and_sampling():
+    tc = TEXT_CASES["text_tiny_b1"]
+    g = load_golden(tc.name)
+    model = _model(tc)
+    past, kvlens, ropes = _context(model, tc)
+    gi = model.prepare_start_tokens(kvlens, ropes, NEW_TOKEN_IDS)
+    end = int(g["tokens"][4, 0])
+    first = int((g["tokens"][1:, 0] == end).nonzero()[0]) + 1
+    tokens = model.generate_text(past_key_values=past, max_length=tc.max_length, end_token_id=end, **gi).cpu()
+    assert torch.equal(tokens, g["tokens"][:first])
+    # sampling: valid ids, right shape, temperature -> 0 reproduces greedy
+    torch.manual_seed(0)
+    s = model.generate_text(past_key_values=past, max_length=6, do_sample=True, temperature=1.0, **gi).cpu()
+    assert s.shape == (6, 1) and int(s.min()) >= 0 and int(s.max()) < tc.dims.vocab_size
+    s0 = model.generate_text(past_key_values=past, max_length=6, do_sample=True, temperature=1e-4, **gi).cpu()
+    assert torch.equal(s0, g["tokens"][:6])
+
+
+def test_inferencer_gen_text_and_think():
+    """InterleaveInferencer.gen_text (inferencer.py:215-244) and the think path of interleave_inference."""
+    from bagel_amd.inferencer import InterleaveInferencer
+    tc = TEXT_CASES["text_tiny_b1"]
+    g = load_golden(tc.name)
+    model = _model(tc)
+
+    class Tok(_Tok):
+        def decode(self, ids):
+            return "<|im_start|>" + " ".join(str(int(i)) for i in ids[1:]) + "<|im_end|>"
+
+    inf = InterleaveInferencer(model, None, Tok(), None, None, NEW_TOKEN_IDS)
+    ctx = inf.init_gen_context()
+    ctx = inf.update_context_text(" ".join(map(str, tc.prompts()[0])), ctx)
+    text = inf.gen_text(ctx, max_length=tc.max_length, do_sample=False)
+    assert text == " ".join(str(int(t)) for t in g["tokens"][1:, 0])
+    out = inf.interleave_inference([" ".join(map(str, tc.prompts()[0]))], understanding_output=True, do_sample=False,
+                                   max_think_token_n=tc.max_length)
+    assert out == [text]
