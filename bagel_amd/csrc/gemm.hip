@@ -55,15 +55,14 @@ static int launch_gemm(GemmParams p, int epilogue, hipStream_t stream) {
   return 0;
 }
 
-template <int FAMILY>
-static int launch_gemm256(GemmParams p, int epilogue, hipStream_t stream) {
+static int launch_pingpong(GemmParams p, int epilogue, hipStream_t stream) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
   const dim3 grid(p.tiles_m * p.tiles_n), block(512);
   const size_t lds = 2 * (256 + 256) * ROW_BYTES;
 #define LAUNCH(EPI)                                                                              \
   do {                                                                                           \
-    auto kern = FAMILY == 0 ? gemm256_pingpong_kernel<EPI> : gemm256_pipelined_kernel<EPI>;      \
+    auto kern = gemm256_pingpong_kernel<EPI>;                                                    \
     static bool configured = false;                                                              \
     if (!configured) {                                                                           \
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -82,6 +81,65 @@ static int launch_gemm256(GemmParams p, int epilogue, hipStream_t stream) {
 #undef LAUNCH
   BAGEL_LAUNCH_CHECK();
   return 0;
+}
+
+template <int BN, int WR>
+static int launch_pipelined(GemmParams p, int epilogue, hipStream_t stream) {
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const dim3 grid(p.tiles_m * p.tiles_n), block(512);
+  const size_t lds = 2 * (256 + BN) * ROW_BYTES;
+  constexpr bool PAIRS = (BN / (8 / WR) / 16) % 2 == 0;  // SwiGLU needs an even number of fragments per wave
+#define LAUNCH(EPI)                                                                              \
+  do {                                                                                           \
+    auto kern = gemm256_pipelined_kernel<EPI, BN, WR>;                                           \
+    static bool configured = false;                                                              \
+    if (!configured) {                                                                           \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      configured = true;                                                                         \
+    }                                                                                            \
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, p);                                       \
+  } while (0)
+  switch (epilogue) {
+    case EPI_BIAS: LAUNCH(EPI_BIAS); break;
+    case EPI_RESIDUAL: LAUNCH(EPI_RESIDUAL); break;
+    case EPI_SWIGLU:
+      if constexpr (PAIRS) {
+        LAUNCH(EPI_SWIGLU);
+        break;
+      } else {
+        bagel_set_error("bagel_gemm_bf16: this tile shape has no SwiGLU epilogue");
+        return 1;
+      }
+    case EPI_BIAS_RESIDUAL: LAUNCH(EPI_BIAS_RESIDUAL); break;
+    case EPI_F32_SCALED: LAUNCH(EPI_F32_SCALED); break;
+    default: bagel_set_error("bagel_gemm_bf16: unknown epilogue %d", epilogue); return 1;
+  }
+#undef LAUNCH
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}
+
+// Tile shape for a problem: the cheapest of the candidates, where a shape costs (rounds of workgroups over
+// the 256 CUs) x (time of one round, in units of 256-wide pipelined tile columns).  The 128x128 kernel
+// runs two workgroups per CU at about 0.77 of the pipelined kernel's rate.
+static int choose_gemm_variant(int M, int N, int epilogue) {
+  const long tm = (M + 255) / 256;
+  auto rounds = [](long tiles, long per_round) { return (tiles + per_round - 1) / per_round; };
+  double best = (double)rounds((long)((M + 127) / 128) * ((N + 127) / 128), 512) * 166.0;
+  int variant = 0;
+  const int bn[3] = {256, 224, 288}, id[3] = {3, 4, 5};
+  for (int c = 0; c < 3; ++c) {
+    if (c > 0 && epilogue == EPI_SWIGLU) continue;
+    const double cost = (double)rounds(tm * ((N + bn[c] - 1) / bn[c]), 256) * bn[c];
+    if (cost < best) {
+      best = cost;
+      variant = id[c];
+    }
+  }
+  // SwiGLU (gate+up, the widest N): the 4 x 2 wave layout measured 2-4 % faster than 2 x 4 on the same tile
+  if (variant == 3 && epilogue == EPI_SWIGLU) variant = 6;
+  return variant;
 }
 
 extern "C" int bagel_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N,
@@ -107,15 +165,17 @@ extern "C" int bagel_gemm_bf16(const void* A, long lda, const void* W, long ldw,
   p.bias = (const bf16*)bias;
   p.R = (const bf16*)residual; p.ldr = ldr;
   p.M = M; p.N = N; p.K = K; p.alpha = alpha;
-  // 256x256 software-pipelined tiles (8 waves, one workgroup per CU) once they fill the chip; 128x128 tiles
-  // (4 waves, two workgroups per CU) for smaller problems.  Measured on the 7B gate+up shape (random
-  // operands): 128x128 1.10, 256x256 one-barrier loop 1.25, ping-pong 1.29, software-pipelined 1.38 PFLOP/s.
-  const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  const int variant = g_gemm_variant >= 0 ? g_gemm_variant : (tiles256 >= 256 ? 3 : 0);
+  // 256-row software-pipelined tiles (8 waves, one workgroup per CU) or 128x128 tiles (4 waves, two
+  // workgroups per CU).  Measured on the 7B gate+up shape (random operands): 128x128 1.10, 256x256
+  // one-barrier loop 1.25, ping-pong 1.29, software-pipelined 1.38 PFLOP/s.
+  const int variant = g_gemm_variant >= 0 ? g_gemm_variant : choose_gemm_variant(M, N, epilogue);
   switch (variant) {
     case 1: return launch_gemm<256, 256, 2, 4>(p, epilogue, (hipStream_t)stream);
-    case 2: return launch_gemm256<0>(p, epilogue, (hipStream_t)stream);
-    case 3: return launch_gemm256<1>(p, epilogue, (hipStream_t)stream);
+    case 2: return launch_pingpong(p, epilogue, (hipStream_t)stream);
+    case 3: return launch_pipelined<256, 2>(p, epilogue, (hipStream_t)stream);
+    case 4: return launch_pipelined<224, 4>(p, epilogue, (hipStream_t)stream);
+    case 5: return launch_pipelined<288, 4>(p, epilogue, (hipStream_t)stream);
+    case 6: return launch_pipelined<256, 4>(p, epilogue, (hipStream_t)stream);
     default: return launch_gemm<128, 128, 2, 2>(p, epilogue, (hipStream_t)stream);
   }
 }

@@ -18,10 +18,19 @@
 #pragma once
 #include "gemm_tile.h"
 
-template <int EPI>
+// BN: tile width in output features (a multiple of 16 * (8 / WR)); WR: waves along M (2 or 4).
+// <256, 2> is the general shape (wave tile 128 x 64).  <224, 4> and <288, 4> (wave tile 64 x 112 / 64 x 144)
+// exist because the tile count should be a whole number of 256-CU rounds: with 12288 rows, N = 3584 is
+// 2.6 rounds of 256-wide tiles but exactly 3 rounds of 224-wide ones, N = 4608 is 3.4 rounds of 256-wide
+// tiles but exactly 3 of 288-wide ones.
+template <int EPI, int BN, int WR>
 __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
-  constexpr int BM = 256, BN = 256, NW = 8, TM = 128, TN = 64, FM = 8, FN = 4;
+  constexpr int BM = 256, NW = 8, WC = NW / WR, TM = BM / WR, TN = BN / WC, FM = TM / 16, FN = TN / 16, FH = FM / 2;
+  static_assert(TN % 16 == 0 && FM % 2 == 0 && BN % 8 == 0, "wave tile must be whole 16x16 fragments");
+  static_assert(EPI != EPI_SWIGLU || FN % 2 == 0, "SwiGLU pairs gate and up fragments");
   constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES, STAGE_BYTES = A_BYTES + W_BYTES;
+  constexpr int W_PIECES = BN / 8, W_ITERS = (W_PIECES + NW - 1) / NW;  // 1-KiB DMA pieces of the W tile
+  constexpr bool W_EVEN = W_PIECES % NW == 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   int tile_m, tile_n;
@@ -29,16 +38,20 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
+  const int wr = wave / WC, wc = wave % WC;
 
   const int piece_row = lane >> 3;
   const int src_chunk = (lane & 7) ^ piece_row;
   const bf16* a_src[4];
-  const bf16* w_src[4];
+  const bf16* w_src[W_ITERS];
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int row = (it * NW + wave) * 8 + piece_row;
     a_src[it] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + src_chunk * 8;
+  }
+#pragma unroll
+  for (int it = 0; it < W_ITERS; ++it) {
+    const int row = (it * NW + wave) * 8 + piece_row;
     w_src[it] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + src_chunk * 8;
   }
   auto stage_a = [&](int kt) {
@@ -50,8 +63,9 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
   auto stage_w = [&](int kt) {
     char* base = smem + (kt & 1) * STAGE_BYTES + A_BYTES;
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
-      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(w_src[it] + kt * BK), LDS_PTR(base + (it * NW + wave) * 1024), 16, 0, 0);
+    for (int it = 0; it < W_ITERS; ++it)
+      if (W_EVEN || it + 1 < W_ITERS || it * NW + wave < W_PIECES)  // wave-uniform
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(w_src[it] + kt * BK), LDS_PTR(base + (it * NW + wave) * 1024), 16, 0, 0);
   };
 
   const int frow = lane & 15, fq = lane >> 4;
@@ -69,10 +83,10 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  bf16x8 af[2][4], wf[2][FN];
+  bf16x8 af[2][FH], wf[2][FN];
   auto read_a = [&](const char* base, int set, int mh, int kk) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) af[set][j] = *(const bf16x8*)(base + a_off[kk] + (mh * 64 + j * 16) * ROW_BYTES);
+    for (int j = 0; j < FH; ++j) af[set][j] = *(const bf16x8*)(base + a_off[kk] + (mh * FH + j) * 16 * ROW_BYTES);
   };
   auto read_w = [&](const char* base, int kk) {
 #pragma unroll
@@ -83,8 +97,8 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < FN; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][mh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], af[set][j], acc[i][mh * 4 + j], 0, 0, 0);
+      for (int j = 0; j < FH; ++j)
+        acc[i][mh * FH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], af[set][j], acc[i][mh * FH + j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -92,11 +106,18 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
   // prologue: tiles 0 and 1 in flight, tile 0 published, phase-0 fragments of tile 0 in registers
   stage_a(0);
   stage_w(0);
-  if (nk > 1) {
+  if (nk > 1 && W_EVEN) {
     stage_a(1);
     stage_w(1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 8 pieces of tile 0; tile 1 stays in flight
+    // the pieces of tile 0 have landed once only tile 1's are outstanding
+    if constexpr (4 + W_ITERS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (4 + W_ITERS == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
+    if (nk > 1) {
+      stage_a(1);
+      stage_w(1);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();

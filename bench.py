@@ -191,7 +191,7 @@ def main():
             ach = flops / (avg * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                               "kernel": "gemm_bf16_nt_kernel<EPI_SWIGLU> (gen-expert gate+up projection)",
+                               "kernel": "gemm256_pipelined_kernel<EPI_SWIGLU, 256, 4> (gen-expert gate+up projection)",
                                "launches_timed": len(ms), "avg_launch_ms": avg, "avg_flops_per_launch": flops}
         if not args.no_cpu_baseline and args.layers is None:
             out["cpu_baseline"] = cpu_baseline(dims, res, args.num_timesteps)

@@ -283,13 +283,24 @@ def test_error_reporting():
         k.gemm(A, A, torch.zeros((8, 8), dtype=BF16, device=DEV))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("M,N,K,epi", [(700, 512, 256, "bias"), (512, 768, 1024, "residual"), (300, 1024, 192, "swiglu"),
-                                       (4096, 4608, 3584, "bias"), (256, 256, 64, "bias"), (260, 256, 128, "residual")])
+                                       (4096, 4608, 3584, "bias"), (256, 256, 64, "bias"), (260, 256, 128, "residual"),
+                                       (1024, 3584, 512, "residual"), (520, 228, 64, "bias")])
 def test_gemm_tile_variants(variant, M, N, K, epi):
-    """Every tile variant (128x128, 256x256, 256x256 ping-pong) must give the same answers, ragged M included."""
+    """Every tile variant (128x128, 256x256 one-barrier / ping-pong / pipelined, 256x224, 256x288) must give the
+    same answers, ragged M and N included."""
     k = _K()
     lib = k.lib()
+    if epi == "swiglu" and variant in (4, 5):
+        with pytest.raises(RuntimeError, match="no SwiGLU epilogue"):
+            lib.bagel_set_gemm_variant(variant)
+            try:
+                k.gemm(torch.zeros((M, K), dtype=BF16, device=DEV), torch.zeros((N, K), dtype=BF16, device=DEV),
+                       torch.zeros((M, N // 2), dtype=BF16, device=DEV), epilogue=k.EPI_SWIGLU)
+            finally:
+                lib.bagel_set_gemm_variant(-1)
+        return
     A, W = _rand((M, K), 1.0, 70), _rand((N, K), 0.05, 71)
     acc = A.float() @ W.float().t()
     lib.bagel_set_gemm_variant(variant)

@@ -18,6 +18,9 @@ SHAPES = [  # name, M, N, K, epilogue
     ("qkv", 12288, 4608, 3584, K.EPI_BIAS),
     ("o_proj", 12288, 3584, 3584, K.EPI_RESIDUAL),
     ("gate_up_1unit", 4096, 37888, 3584, K.EPI_SWIGLU),
+    ("down_1unit", 4096, 3584, 18944, K.EPI_RESIDUAL),
+    ("qkv_1unit", 4096, 4608, 3584, K.EPI_BIAS),
+    ("o_proj_1unit", 4096, 3584, 3584, K.EPI_RESIDUAL),
 ]
 
 
@@ -39,13 +42,17 @@ def main():
                 lib.bagel_set_gemm_variant(v)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(3):
-                    K.gemm(A, W, C, bias=b, residual=R, epilogue=epi)
+                try:
+                    for _ in range(3):
+                        K.gemm(A, W, C, bias=b, residual=R, epilogue=epi)
+                except RuntimeError:      # this tile shape does not implement the epilogue
+                    times.pop(v, None)
+                    continue
                 e1.record()
                 torch.cuda.synchronize()
-                if r > 0:
+                if r > 0 and v in times:
                     times[v].append(e0.elapsed_time(e1) / 3)
-        for v in variants:
+        for v in [v for v in variants if times.get(v)]:
             t = sorted(times[v])
             med = t[len(t) // 2]
             print(f"{name:14s} variant {v}: median {med:.3f} ms  {flops / med / 1e9:.0f} TFLOP/s   min {t[0]:.3f} ms {flops / t[0] / 1e9:.0f} TFLOP/s",
