@@ -9,7 +9,7 @@ host code and the CPU checker.
 from __future__ import annotations
 
 from dataclasses import dataclass, field, asdict
-from typing import Tuple
+from typing import Optional, Tuple
 
 
 @dataclass(frozen=True)
@@ -25,6 +25,28 @@ class VAEDims:
     z_channels: int = 16
     scale_factor: float = 0.3611
     shift_factor: float = 0.1159
+
+
+@dataclass(frozen=True)
+class ViTDims:
+    """SigLIP NaViT tower as BAGEL configures it (/root/reference/app.py:45-48: so400m-patch14 at 980 px with
+    rope off and the last layer dropped; head_dim 72)."""
+    hidden_size: int = 1152
+    intermediate_size: int = 4304
+    num_layers: int = 26
+    num_heads: int = 16
+    patch_size: int = 14
+    num_channels: int = 3
+    max_patches_per_side: int = 70
+    layer_norm_eps: float = 1e-6
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_heads
+
+    @property
+    def patch_dim(self) -> int:
+        return self.num_channels * self.patch_size ** 2
 
 
 @dataclass(frozen=True)
@@ -46,6 +68,7 @@ class BagelDims:
     max_latent_size: int = 64
     timestep_freq_dim: int = 256
     vae: VAEDims = field(default_factory=VAEDims)
+    vit: Optional[ViTDims] = None      # None: no understanding tower (image inputs unavailable)
 
     @property
     def head_dim(self) -> int:
@@ -77,19 +100,24 @@ class BagelDims:
         return asdict(self)
 
 
-# Public BAGEL-7B-MoT dims (Qwen2.5-7B backbone).
-BAGEL_7B = BagelDims()
+# Public BAGEL-7B-MoT dims (Qwen2.5-7B backbone, SigLIP so400m tower).
+BAGEL_7B = BagelDims(vit=ViTDims())
 
 # Qwen2-0.5B-shaped MoT used by the CPU-runnable plumbing configuration.
 BAGEL_0P5B = BagelDims(hidden_size=896, intermediate_size=4864, num_layers=24,
                        num_heads=14, num_kv_heads=2, vocab_size=151936)
 
 
-def tiny_dims(num_layers: int = 2, vocab_size: int = 512, max_latent_size: int = 64) -> BagelDims:
+def tiny_vit() -> ViTDims:
+    """Two heads of the real head_dim (72), an intermediate size that is not a multiple of 64 (like 4304)."""
+    return ViTDims(hidden_size=144, intermediate_size=272, num_layers=2, num_heads=2, max_patches_per_side=8)
+
+
+def tiny_dims(num_layers: int = 2, vocab_size: int = 512, max_latent_size: int = 64, vit: bool = False) -> BagelDims:
     """Smallest shape that still exercises GQA (2 q heads per kv head) at head_dim 128."""
     return BagelDims(hidden_size=256, intermediate_size=512, num_layers=num_layers,
                      num_heads=2, num_kv_heads=1, vocab_size=vocab_size,
-                     max_latent_size=max_latent_size)
+                     max_latent_size=max_latent_size, vit=tiny_vit() if vit else None)
 
 
 def width7b_dims(num_layers: int = 2, vocab_size: int = 512) -> BagelDims:

@@ -20,7 +20,7 @@ from typing import Dict, Iterator, Tuple
 import numpy as np
 import torch
 
-from .config import BagelDims, VAEDims
+from .config import BagelDims, VAEDims, ViTDims
 
 
 def _gen(seed: int, name: str) -> torch.Generator:
@@ -118,6 +118,102 @@ def make_llm_state_dict(dims: BagelDims, seed: int = 0, device="cpu",
     pe = get_2d_sincos_pos_embed(H, dims.max_latent_size)
     sd["latent_pos_embed.pos_embed"] = torch.from_numpy(pe).float().to(torch.bfloat16).to(device)
     return sd
+
+
+def make_vit_state_dict(dims: BagelDims, seed: int = 0, device="cpu") -> Dict[str, torch.Tensor]:
+    """bf16 weights of the SigLIP tower (patch embedding already in its linear form,
+    siglip_navit.py:167-182), the connector and ``vit_pos_embed`` (bagel.py:82-87).
+    Matrices ~ N(0, 1/fan_in) so activations keep unit scale; LayerNorm affine ~ N(1, 0.1) / N(0, 0.1)."""
+    vit: ViTDims = dims.vit
+    Hv, Iv, H = vit.hidden_size, vit.intermediate_size, dims.hidden_size
+    sd: Dict[str, torch.Tensor] = {}
+
+    def lin(name, nout, nin, gain=1.0):
+        sd[name + ".weight"] = _randn(seed, name + ".weight", (nout, nin), gain * nin ** -0.5).to(device)
+        sd[name + ".bias"] = _randn(seed, name + ".bias", (nout,), 0.1).to(device)
+
+    def ln(name, n):
+        sd[name + ".weight"] = _randn(seed, name + ".weight", (n,), 0.1, 1.0).to(device)
+        sd[name + ".bias"] = _randn(seed, name + ".bias", (n,), 0.1).to(device)
+
+    pre = "vit_model.vision_model."
+    lin(pre + "embeddings.patch_embedding", Hv, vit.patch_dim)
+    sd[pre + "embeddings.position_embedding.weight"] = _randn(
+        seed, pre + "embeddings.position_embedding.weight", (vit.max_patches_per_side ** 2, Hv), 0.5).to(device)
+    for i in range(vit.num_layers):
+        l = pre + f"encoder.layers.{i}."
+        ln(l + "layer_norm1", Hv)
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            lin(l + "self_attn." + n, Hv, Hv)
+        ln(l + "layer_norm2", Hv)
+        lin(l + "mlp.fc1", Iv, Hv)
+        lin(l + "mlp.fc2", Hv, Iv)
+    ln(pre + "post_layernorm", Hv)
+    lin("connector.fc1", H, Hv)
+    lin("connector.fc2", H, H, gain=0.5)
+    pe = get_2d_sincos_pos_embed(H, vit.max_patches_per_side)
+    sd["vit_pos_embed.pos_embed"] = torch.from_numpy(pe).float().to(torch.bfloat16).to(device)
+    return sd
+
+
+def vae_encoder_param_shapes(v: VAEDims) -> Dict[str, Tuple[int, ...]]:
+    """Parameter names/shapes of ``AutoEncoder.encoder`` (autoencoder.py:122-170)."""
+    shapes: Dict[str, Tuple[int, ...]] = {}
+
+    def conv(name, cin, cout, k):
+        shapes[name + ".weight"] = (cout, cin, k, k)
+        shapes[name + ".bias"] = (cout,)
+
+    def norm(name, c):
+        shapes[name + ".weight"] = (c,)
+        shapes[name + ".bias"] = (c,)
+
+    def res(name, cin, cout):
+        norm(name + ".norm1", cin)
+        conv(name + ".conv1", cin, cout, 3)
+        norm(name + ".norm2", cout)
+        conv(name + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(name + ".nin_shortcut", cin, cout, 1)
+
+    nres = len(v.ch_mult)
+    conv("encoder.conv_in", v.in_channels, v.ch, 3)
+    in_mult = (1,) + tuple(v.ch_mult)
+    block_in = v.ch
+    for lvl in range(nres):
+        block_in = v.ch * in_mult[lvl]
+        block_out = v.ch * v.ch_mult[lvl]
+        for b in range(v.num_res_blocks):
+            res(f"encoder.down.{lvl}.block.{b}", block_in, block_out)
+            block_in = block_out
+        if lvl != nres - 1:
+            conv(f"encoder.down.{lvl}.downsample.conv", block_in, block_in, 3)
+    res("encoder.mid.block_1", block_in, block_in)
+    norm("encoder.mid.attn_1.norm", block_in)
+    for n in ("q", "k", "v", "proj_out"):
+        conv(f"encoder.mid.attn_1.{n}", block_in, block_in, 1)
+    res("encoder.mid.block_2", block_in, block_in)
+    norm("encoder.norm_out", block_in)
+    conv("encoder.conv_out", block_in, 2 * v.z_channels, 3)
+    return shapes
+
+
+def _make_vae_state_dict(shapes, seed, device):
+    sd: Dict[str, torch.Tensor] = {}
+    for name, shape in shapes.items():
+        if len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            sd[name] = _randn(seed, name, shape, fan_in ** -0.5, dtype=torch.float32).to(device)
+        elif ".norm" in name and name.endswith(".weight"):
+            sd[name] = _randn(seed, name, shape, 0.1, 1.0, dtype=torch.float32).to(device)
+        else:
+            sd[name] = _randn(seed, name, shape, 0.1, dtype=torch.float32).to(device)
+    return sd
+
+
+def make_vae_encoder_state_dict(v: VAEDims, seed: int = 0, device="cpu") -> Dict[str, torch.Tensor]:
+    """fp32 encoder weights, drawn like the decoder's."""
+    return _make_vae_state_dict(vae_encoder_param_shapes(v), seed, device)
 
 
 def vae_decoder_param_shapes(v: VAEDims) -> Dict[str, Tuple[int, ...]]:

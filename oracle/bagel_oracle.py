@@ -618,3 +618,206 @@ def unpatchify_latent(dims, latent: torch.Tensor, image_shape) -> torch.Tensor:
 def to_uint8_image(image: torch.Tensor) -> torch.Tensor:
     """inferencer.py:209-210."""
     return ((image * 0.5 + 0.5).clamp(0, 1)[0].permute(1, 2, 0) * 255).to(torch.uint8)
+
+
+# ----------------------------------------------------------------------------
+# SigLIP NaViT vision tower + connector (image understanding tokens)
+# ----------------------------------------------------------------------------
+def layer_norm(x, w, b, eps):
+    """nn.LayerNorm under autocast: fp32 statistics and affine; the consumer rounds the result to bf16."""
+    return F.layer_norm(x.float(), (x.shape[-1],), w.float(), b.float(), eps)
+
+
+def gelu_tanh(x):
+    """ACT2FN["gelu_pytorch_tanh"] on a bf16 tensor: fp32 math, result in the input dtype."""
+    return F.gelu(x.float(), approximate="tanh").to(x.dtype)
+
+
+def patchify(image, patch_size):
+    """data/data_utils.py:43-50."""
+    c, h, w = image.shape
+    q = patch_size
+    image = image.reshape(c, h // q, q, w // q, q)
+    return torch.einsum("chpwq->hwpqc", image).reshape(-1, q * q * c)
+
+
+def siglip_forward(p, vit, packed_pixel_values, packed_flattened_position_ids, seqlens):
+    """SiglipVisionModel.forward with rope off and the patch embedding converted to a linear layer
+    (siglip_navit.py:167-195, 202-244, 255-300, 345-371).  ``vit`` is a ViTDims."""
+    pre = "vit_model.vision_model."
+    Hh, D = vit.num_heads, vit.hidden_size // vit.num_heads
+    x = linear(packed_pixel_values, p[pre + "embeddings.patch_embedding.weight"], p[pre + "embeddings.patch_embedding.bias"])
+    x = x + p[pre + "embeddings.position_embedding.weight"].to(BF16)[packed_flattened_position_ids]
+    lens = [int(n) for n in seqlens]
+    for i in range(vit.num_layers):
+        l = pre + f"encoder.layers.{i}."
+        h = layer_norm(x, p[l + "layer_norm1.weight"], p[l + "layer_norm1.bias"], vit.layer_norm_eps)
+        q = linear(h, p[l + "self_attn.q_proj.weight"], p[l + "self_attn.q_proj.bias"]).view(-1, Hh, D)
+        k = linear(h, p[l + "self_attn.k_proj.weight"], p[l + "self_attn.k_proj.bias"]).view(-1, Hh, D)
+        v = linear(h, p[l + "self_attn.v_proj.weight"], p[l + "self_attn.v_proj.bias"]).view(-1, Hh, D)
+        o = varlen_attention(q, k, v, lens, lens, causal=False).reshape(-1, Hh * D)
+        x = x + linear(o, p[l + "self_attn.out_proj.weight"], p[l + "self_attn.out_proj.bias"])
+        h = layer_norm(x, p[l + "layer_norm2.weight"], p[l + "layer_norm2.bias"], vit.layer_norm_eps)
+        h = gelu_tanh(linear(h, p[l + "mlp.fc1.weight"], p[l + "mlp.fc1.bias"]))
+        x = x + linear(h, p[l + "mlp.fc2.weight"], p[l + "mlp.fc2.bias"])
+    return layer_norm(x, p[pre + "post_layernorm.weight"], p[pre + "post_layernorm.bias"], vit.layer_norm_eps)
+
+
+def vit_token_embed(p, vit, packed_vit_tokens, packed_vit_position_ids, vit_token_seqlens):
+    """vit_model -> connector -> + vit_pos_embed, bagel.py:974-987 (MLPconnector: modeling_utils.py:115-126)."""
+    h = siglip_forward(p, vit, packed_vit_tokens, packed_vit_position_ids, vit_token_seqlens)
+    h = gelu_tanh(linear(h, p["connector.fc1.weight"], p["connector.fc1.bias"]))
+    h = linear(h, p["connector.fc2.weight"], p["connector.fc2.bias"])
+    return h + p["vit_pos_embed.pos_embed"].to(BF16)[packed_vit_position_ids]
+
+
+def _prepare_image_tokens(curr_kvlens, curr_rope, token_counts, new_token_ids):
+    """Index bookkeeping shared by prepare_vit_images and prepare_vae_images (bagel.py:883-920, 1017-1058)."""
+    img_idx, text_ids, text_idx, seqlens, pos_ids, idx, kvidx = [], [], [], [], [], [], []
+    _curr = curr = 0
+    newlens, new_rope = [], []
+    for n, kvlen, rope in zip(token_counts, curr_kvlens, curr_rope):
+        kvidx.extend(range(curr, curr + kvlen))
+        curr += kvlen
+        text_ids.append(new_token_ids["start_of_image"])
+        text_idx.append(_curr)
+        idx.append(curr)
+        curr += 1
+        _curr += 1
+        img_idx.extend(range(_curr, _curr + n))
+        idx.extend(range(curr, curr + n))
+        curr += n
+        _curr += n
+        text_ids.append(new_token_ids["end_of_image"])
+        text_idx.append(_curr)
+        idx.append(curr)
+        curr += 1
+        _curr += 1
+        pos_ids.extend([rope] * (n + 2))
+        seqlens.append(n + 2)
+        newlens.append(kvlen + n + 2)
+        new_rope.append(rope + 1)
+    gi = {
+        "packed_text_ids": torch.tensor(text_ids, dtype=torch.long),
+        "packed_text_indexes": torch.tensor(text_idx, dtype=torch.long),
+        "packed_position_ids": torch.tensor(pos_ids, dtype=torch.long),
+        "packed_seqlens": torch.tensor(seqlens, dtype=torch.int),
+        "packed_indexes": torch.tensor(idx, dtype=torch.long),
+        "packed_key_value_indexes": torch.tensor(kvidx, dtype=torch.long),
+        "key_values_lens": torch.tensor(curr_kvlens, dtype=torch.int),
+    }
+    return gi, img_idx, newlens, new_rope
+
+
+def prepare_vit_images(dims, curr_kvlens, curr_rope, image_tensors, new_token_ids):
+    """Bagel.prepare_vit_images, bagel.py:876-936, on already transformed [3, H, W] tensors."""
+    vit = dims.vit
+    toks = [patchify(t, vit.patch_size) for t in image_tensors]
+    pos = [flattened_position_ids_extrapolate(t.shape[1], t.shape[2], vit.patch_size, vit.max_patches_per_side)
+           for t in image_tensors]
+    gi, img_idx, newlens, new_rope = _prepare_image_tokens(curr_kvlens, curr_rope, [t.shape[0] for t in toks], new_token_ids)
+    gi.update({
+        "vit_token_seqlens": torch.tensor([t.shape[0] for t in toks], dtype=torch.int),
+        "packed_vit_tokens": torch.cat(toks, dim=0),
+        "packed_vit_position_ids": torch.cat(pos, dim=0),
+        "packed_vit_token_indexes": torch.tensor(img_idx, dtype=torch.long),
+    })
+    return gi, newlens, new_rope
+
+
+def forward_cache_update_vit(p, dims, past, packed_text_ids, packed_text_indexes, packed_vit_tokens,
+                             packed_vit_token_indexes, packed_vit_position_ids, vit_token_seqlens, packed_position_ids,
+                             packed_seqlens, packed_indexes, packed_key_value_indexes, key_values_lens, embed_trace=None):
+    """Bagel.forward_cache_update_vit, bagel.py:938-1008."""
+    emb = p["language_model.model.embed_tokens.weight"][packed_text_ids]
+    seq = emb.new_zeros((int(sum(packed_seqlens)), dims.hidden_size))
+    seq[packed_text_indexes] = emb
+    ve = vit_token_embed(p, dims.vit, packed_vit_tokens, packed_vit_position_ids, vit_token_seqlens).to(seq.dtype)
+    if embed_trace is not None:
+        embed_trace.append(ve)
+    seq[packed_vit_token_indexes] = ve
+    _, past = llm_forward_inference(p, dims, seq, packed_seqlens, packed_position_ids, packed_indexes, past,
+                                    key_values_lens, packed_key_value_indexes, update_past_key_values=True,
+                                    is_causal=False, mode="und")
+    return past
+
+
+# ----------------------------------------------------------------------------
+# FLUX VAE encoder and the VAE-token prefill
+# ----------------------------------------------------------------------------
+def vae_encode_moments(p, vdims, x: torch.Tensor, bf16: bool = True) -> torch.Tensor:
+    """Encoder.forward, autoencoder.py:172-193: [B, 3, H, W] -> [B, 2 z, H/8, W/8] (mean | logvar)."""
+    h = _conv(x, p, "encoder.conv_in", 1, bf16)
+    nres = len(vdims.ch_mult)
+    for lvl in range(nres):
+        for b in range(vdims.num_res_blocks):
+            h = _resblock(h, p, f"encoder.down.{lvl}.block.{b}", bf16)
+        if lvl != nres - 1:
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)       # Downsample, autoencoder.py:104-108
+            w, b_ = p[f"encoder.down.{lvl}.downsample.conv.weight"], p[f"encoder.down.{lvl}.downsample.conv.bias"]
+            h = F.conv2d(h.to(BF16), w.to(BF16), b_.to(BF16), stride=2) if bf16 else F.conv2d(h, w, b_, stride=2)
+    h = _resblock(h, p, "encoder.mid.block_1", bf16)
+    h = _attnblock(h, p, "encoder.mid.attn_1", bf16)
+    h = _resblock(h, p, "encoder.mid.block_2", bf16)
+    h = _gn_swish(h, p, "encoder.norm_out")
+    return _conv(h, p, "encoder.conv_out", 1, bf16)
+
+
+def vae_encode(p, vdims, x, noise, bf16: bool = True):
+    """AutoEncoder.encode, autoencoder.py:275-287, 315-318, with the Gaussian draw given by the caller."""
+    mean, logvar = torch.chunk(vae_encode_moments(p, vdims, x, bf16), 2, dim=1)
+    z = mean + torch.exp(0.5 * logvar) * noise.to(mean.dtype)
+    return vdims.scale_factor * (z - vdims.shift_factor)
+
+
+def prepare_vae_images(dims, curr_kvlens, curr_rope, image_tensors, new_token_ids, timestep=0):
+    """Bagel.prepare_vae_images, bagel.py:1010-1081, on already transformed [3, H, W] tensors."""
+    ds = dims.latent_downsample
+    shapes = [(t.shape[1] // ds, t.shape[2] // ds) for t in image_tensors]
+    pos = [flattened_position_ids_extrapolate(t.shape[1], t.shape[2], ds, dims.max_latent_size) for t in image_tensors]
+    gi, img_idx, newlens, new_rope = _prepare_image_tokens(curr_kvlens, curr_rope, [h * w for h, w in shapes], new_token_ids)
+    size = [max(s) for s in zip(*[t.shape for t in image_tensors])]
+    padded = torch.zeros((len(image_tensors), *size))
+    for i, t in enumerate(image_tensors):
+        padded[i, :, :t.shape[1], :t.shape[2]] = t
+    gi.update({
+        "padded_images": padded,
+        "patchified_vae_latent_shapes": shapes,
+        "packed_vae_position_ids": torch.cat(pos, dim=0),
+        "packed_timesteps": torch.tensor([timestep]),
+        "packed_vae_token_indexes": torch.tensor(img_idx, dtype=torch.long),
+    })
+    return gi, newlens, new_rope
+
+
+def forward_cache_update_vae(p, vae_p, dims, past, padded_images, patchified_vae_latent_shapes, packed_vae_position_ids,
+                             packed_timesteps, packed_vae_token_indexes, packed_text_ids, packed_text_indexes,
+                             packed_position_ids, packed_seqlens, packed_indexes, key_values_lens,
+                             packed_key_value_indexes, noise, latent_trace=None):
+    """Bagel.forward_cache_update_vae, bagel.py:1083-1143."""
+    emb = p["language_model.model.embed_tokens.weight"][packed_text_ids]
+    seq = emb.new_zeros((int(sum(packed_seqlens)), dims.hidden_size))
+    seq[packed_text_indexes] = emb
+    padded_latent = vae_encode(vae_p, dims.vae, padded_images, noise)
+    q, c = dims.latent_patch_size, dims.latent_channel
+    packed = []
+    for latent, (h, w) in zip(padded_latent, patchified_vae_latent_shapes):
+        latent = latent[:, :h * q, :w * q].reshape(c, h, q, w, q)
+        packed.append(torch.einsum("chpwq->hwpqc", latent).reshape(-1, q * q * c))
+    packed = torch.cat(packed, dim=0)
+    if latent_trace is not None:
+        latent_trace.append(packed)
+    t = packed_timesteps
+    half = dims.timestep_freq_dim // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(t.dtype)
+    args = t[:, None] * freqs[None]                       # modeling_utils.py:98-103 (freqs take t's dtype)
+    f = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    te = linear(F.silu(linear(f, p["time_embedder.mlp.0.weight"], p["time_embedder.mlp.0.bias"])),
+                p["time_embedder.mlp.2.weight"], p["time_embedder.mlp.2.bias"])
+    lat = linear(packed, p["vae2llm.weight"], p["vae2llm.bias"]) + te + p["latent_pos_embed.pos_embed"][packed_vae_position_ids]
+    seq[packed_vae_token_indexes] = lat.to(seq.dtype)
+    _, past = llm_forward_inference(p, dims, seq, packed_seqlens, packed_position_ids, packed_indexes, past,
+                                    key_values_lens, packed_key_value_indexes, update_past_key_values=True,
+                                    is_causal=False, mode="gen", packed_vae_token_indexes=packed_vae_token_indexes,
+                                    packed_text_indexes=packed_text_indexes)
+    return past

@@ -28,9 +28,10 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 import ref_harness as rh  # noqa: E402
-from scenarios import SCENARIOS, TEXT_CASES, NEW_TOKEN_IDS  # noqa: E402
+from scenarios import SCENARIOS, TEXT_CASES, IMAGE_CTX_CASES, NEW_TOKEN_IDS  # noqa: E402
 from bagel_amd.config import VAEDims  # noqa: E402
-from bagel_amd.weights import make_llm_state_dict, make_vae_decoder_state_dict  # noqa: E402
+from bagel_amd.weights import (make_llm_state_dict, make_vae_decoder_state_dict, make_vae_encoder_state_dict,  # noqa: E402
+                               make_vit_state_dict)
 
 
 def build_context(model, NaiveCache, prompts, n_samples, tok):
@@ -162,6 +163,120 @@ def run_text_case(tc):
     print(f"[{tc.name}] tokens {tokens.T.tolist()} in {time.time() - t0:.1f}s")
 
 
+def run_image_ctx_case(ic):
+    """Reference prepare_vae_images / forward_cache_update_vae / prepare_vit_images / forward_cache_update_vit on a
+    packed batch (identity stand-in for the image transforms), then, for an edit case, generate_image with the
+    editing path's three CFG contexts."""
+    import copy
+    t0 = time.time()
+    sd = make_llm_state_dict(ic.dims, seed=ic.weight_seed)
+    sd.update(make_vit_state_dict(ic.dims, seed=ic.weight_seed))
+    model = rh.build_reference_model(ic.dims, sd)
+    vd = ic.dims.vae
+    vsd = make_vae_encoder_state_dict(vd, seed=0)
+    vsd.update(make_vae_decoder_state_dict(vd, seed=0))
+    vae = rh.build_reference_vae(vd, vsd)
+    from modeling.bagel.qwen2_navit import NaiveCache
+    tok = rh.StandInTokenizer()
+    ident = lambda x: x  # noqa: E731
+    n = ic.batch
+    out = {}
+    L = ic.dims.num_layers
+
+    def snap(tag, past):
+        out[f"{tag}.k0"] = past.key_cache[0].clone()
+        out[f"{tag}.v0"] = past.value_cache[0].clone()
+        out[f"{tag}.k_last"] = past.key_cache[L - 1].clone()
+        out[f"{tag}.v_last"] = past.value_cache[L - 1].clone()
+
+    with torch.no_grad(), rh.autocast():
+        past = NaiveCache(L)
+        kvlens, ropes = [0] * n, [0] * n
+        if ic.first_prompt is not None:
+            gi, kvlens, ropes = model.prepare_prompts(kvlens, ropes, [" ".join(map(str, p)) for p in ic.prompts("first")],
+                                                      tok, NEW_TOKEN_IDS)
+            past = model.forward_cache_update_text(past, **gi)
+        if ic.vae_images is not None:
+            gi, kvlens, ropes = model.prepare_vae_images(kvlens, ropes, ic.images("vae"), ident, NEW_TOKEN_IDS)
+            hooks = [vae.encoder.register_forward_hook(lambda m, i, o: out.__setitem__("vae.moments", o.float().clone()))]
+            real_randn_like = torch.randn_like
+
+            def randn_like(x, *a, **k):
+                r = real_randn_like(x, *a, **k)
+                out["vae.noise"] = r.float().clone()
+                return r
+
+            torch.manual_seed(ic.noise_seed)
+            torch.randn_like = randn_like
+            try:
+                past = model.forward_cache_update_vae(vae, past, **gi)
+            finally:
+                torch.randn_like = real_randn_like
+                for h in hooks:
+                    h.remove()
+            snap("after_vae", past)
+        ctx_before_vit = None
+        if ic.vit_images is not None:
+            gi, kvlens, ropes = model.prepare_vit_images(kvlens, ropes, ic.images("vit"), ident, NEW_TOKEN_IDS)
+            hooks = [model.vit_model.register_forward_hook(lambda m, i, o: out.__setitem__("vit.tower", o.float().clone())),
+                     model.connector.register_forward_hook(lambda m, i, o: out.__setitem__("vit.connector", o.float().clone()))]
+            past = model.forward_cache_update_vit(past, **gi)
+            for h in hooks:
+                h.remove()
+            snap("after_vit", past)
+        out["kv_lens"] = torch.tensor(kvlens)
+        out["ropes"] = torch.tensor(ropes)
+        if ic.edit_prompt is not None:
+            # editing path of interleave_inference (inferencer.py:281-292): the text-free context is the one
+            # before the prompt; the image-free context holds the prompt alone
+            text_ctx = (copy.deepcopy(past), list(kvlens), list(ropes))
+            prompts = [" ".join(map(str, p)) for p in ic.prompts("edit")]
+            gi, kvlens, ropes = model.prepare_prompts(kvlens, ropes, prompts, tok, NEW_TOKEN_IDS)
+            past = model.forward_cache_update_text(past, **gi)
+            gi2, ikv, irope = model.prepare_prompts([0] * n, [0] * n, prompts, tok, NEW_TOKEN_IDS)
+            img_past = model.forward_cache_update_text(NaiveCache(L), **gi2)
+            torch.manual_seed(ic.noise_seed + 1)
+            sizes = [ic.out_image] * n
+            g = model.prepare_vae_latent(kvlens, ropes, sizes, NEW_TOKEN_IDS)
+            gt = model.prepare_vae_latent_cfg(text_ctx[1], text_ctx[2], sizes)
+            gm = model.prepare_vae_latent_cfg(ikv, irope, sizes)
+            out["edit.init_noise"] = g["packed_init_noises"].clone()
+            steps, branch_v = [], []
+            vae_idx = g["packed_vae_token_indexes"]
+            hook = model.llm2vae.register_forward_hook(lambda m, i, o: branch_v.append(o[vae_idx].clone()))
+            orig_flow = model._forward_flow
+
+            def flow(**kw):
+                branch_v.clear()
+                v = orig_flow(**kw)
+                steps.append({"x_t": kw["x_t"].clone(), "v_t": v.clone(), "v_cond": branch_v[0], "v_text": branch_v[1],
+                              "v_img": branch_v[2]})
+                return v
+
+            model._forward_flow = flow
+            latents = model.generate_image(
+                past_key_values=past, num_timesteps=ic.num_timesteps, timestep_shift=3.0, cfg_renorm_min=0.0,
+                cfg_renorm_type="text_channel", cfg_interval=[0.0, 1.0], cfg_text_scale=4.0,
+                cfg_text_past_key_values=text_ctx[0], cfg_text_packed_position_ids=gt["cfg_packed_position_ids"],
+                cfg_text_packed_query_indexes=gt["cfg_packed_query_indexes"],
+                cfg_text_key_values_lens=gt["cfg_key_values_lens"],
+                cfg_text_packed_key_value_indexes=gt["cfg_packed_key_value_indexes"],
+                cfg_img_scale=2.0, cfg_img_past_key_values=img_past,
+                cfg_img_packed_position_ids=gm["cfg_packed_position_ids"],
+                cfg_img_packed_query_indexes=gm["cfg_packed_query_indexes"],
+                cfg_img_key_values_lens=gm["cfg_key_values_lens"],
+                cfg_img_packed_key_value_indexes=gm["cfg_packed_key_value_indexes"], **g)
+            hook.remove()
+            out["edit.final_latent"] = torch.cat(list(latents), dim=0).clone()
+            for i, rec in enumerate(steps):
+                for k, v in rec.items():
+                    out[f"edit.step{i}.{k}"] = v
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, f"{ic.name}.safetensors"),
+              metadata={"source": "reference Bagel image-context prefill (+ edit generation) on CPU, bf16 weights + bf16 "
+                                  "autocast, fp32 VAE, SDPA stand-in for flash_attn, identity image transforms"})
+    print(f"[{ic.name}] wrote {len(out)} tensors in {time.time() - t0:.1f}s")
+
+
 VAE_CASES = {"vae_128": (16, 16), "vae_256": (32, 32), "vae_512x384": (64, 48)}
 
 
@@ -183,11 +298,13 @@ def run_vae(name, latent_hw):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(SCENARIOS) + list(TEXT_CASES) + list(VAE_CASES))
+    names = sys.argv[1:] or (list(SCENARIOS) + list(TEXT_CASES) + list(IMAGE_CTX_CASES) + list(VAE_CASES))
     for nme in names:
         if nme in SCENARIOS:
             run_llm_scenario(SCENARIOS[nme])
         elif nme in TEXT_CASES:
             run_text_case(TEXT_CASES[nme])
+        elif nme in IMAGE_CTX_CASES:
+            run_image_ctx_case(IMAGE_CTX_CASES[nme])
         else:
             run_vae(nme, VAE_CASES[nme])

@@ -97,11 +97,23 @@ def build_reference_model(dims, state_dict):
                                    ch=v.ch, out_ch=v.out_ch, ch_mult=list(v.ch_mult),
                                    num_res_blocks=v.num_res_blocks, z_channels=v.z_channels,
                                    scale_factor=v.scale_factor, shift_factor=v.shift_factor)
-    config = BagelConfig(visual_gen=True, visual_und=False, llm_config=llm_config, vit_config=None,
+    vit_model, vit_config, extra = None, None, {}
+    if dims.vit is not None:
+        # the tower as app.py:45-48, 96-97 sets it up: rope off, patch embedding converted to a linear layer
+        from modeling.bagel.siglip_navit import SiglipVisionConfig, SiglipVisionModel
+        t = dims.vit
+        vit_config = SiglipVisionConfig(hidden_size=t.hidden_size, intermediate_size=t.intermediate_size,
+                                        num_hidden_layers=t.num_layers, num_attention_heads=t.num_heads,
+                                        num_channels=t.num_channels, image_size=t.patch_size * t.max_patches_per_side,
+                                        patch_size=t.patch_size, layer_norm_eps=t.layer_norm_eps, rope=False)
+        vit_model = SiglipVisionModel(vit_config)
+        vit_model.vision_model.embeddings.convert_conv2d_to_linear(vit_config)
+        extra = dict(vit_max_num_patch_per_side=t.max_patches_per_side, connector_act="gelu_pytorch_tanh")
+    config = BagelConfig(visual_gen=True, visual_und=dims.vit is not None, llm_config=llm_config, vit_config=vit_config,
                          vae_config=vae_config, latent_patch_size=dims.latent_patch_size,
-                         max_latent_size=dims.max_latent_size)
+                         max_latent_size=dims.max_latent_size, **extra)
     lm = Qwen2ForCausalLM(llm_config)
-    model = Bagel(lm, None, config)
+    model = Bagel(lm, vit_model, config)
     missing, unexpected = model.load_state_dict(state_dict, strict=False)
     missing = [m for m in missing if "lm_head" not in m]
     assert not missing and not unexpected, (missing, unexpected)
@@ -124,7 +136,8 @@ def build_reference_vae(vdims, state_dict):
                                shift_factor=vdims.shift_factor)
     ae = AutoEncoder(params)
     missing, unexpected = ae.load_state_dict(state_dict, strict=False)
-    missing = [m for m in missing if not m.startswith("encoder.")]
+    if not any(k.startswith("encoder.") for k in state_dict):
+        missing = [m for m in missing if not m.startswith("encoder.")]
     assert not missing and not unexpected, (missing, unexpected)
     return ae.eval()
 

@@ -96,3 +96,49 @@ TEXT_CASES = {c.name: c for c in [
     TextCase("text_tiny_b2", tiny_dims(3), [12, 40], 10, weight_seed=3),
     TextCase("text_gqa7", _small_gqa(), [33], 8, weight_seed=1),
 ]}
+
+
+@dataclass
+class ImageCtxCase:
+    """Context building with image inputs (bagel.py:876-1143) for a packed batch: optional text prompt, then
+    optional VAE-encoded image, then optional ViT-encoded image, per sample in that order; ``edit`` additionally
+    appends a second prompt and runs image generation with the three CFG contexts of the editing path
+    (inferencer.py:281-292)."""
+    name: str
+    dims: BagelDims
+    first_prompt: Optional[List[int]]
+    vae_images: Optional[List[Tuple[int, int]]]
+    vit_images: Optional[List[Tuple[int, int]]]
+    edit_prompt: Optional[List[int]] = None
+    out_image: Tuple[int, int] = (128, 128)
+    num_timesteps: int = 4
+    weight_seed: int = 0
+    image_seed: int = 11
+    noise_seed: int = 5
+
+    @property
+    def batch(self) -> int:
+        for v in (self.first_prompt, self.vae_images, self.vit_images):
+            if v is not None:
+                return len(v)
+        raise ValueError("empty case")
+
+    def prompts(self, which: str) -> List[List[int]]:
+        lens = self.first_prompt if which == "first" else self.edit_prompt
+        salt = 201 if which == "first" else 307
+        return [_prompt(n, salt + b, self.dims.vocab_size) for b, n in enumerate(lens)]
+
+    def images(self, which: str):
+        """Seeded stand-ins for transformed images: [3, H, W] in [-1, 1]."""
+        import torch
+        sizes = self.vae_images if which == "vae" else self.vit_images
+        g = torch.Generator().manual_seed(self.image_seed + (0 if which == "vae" else 1000))
+        return [torch.rand((3, h, w), generator=g) * 2 - 1 for h, w in sizes]
+
+
+IMAGE_CTX_CASES = {c.name: c for c in [
+    ImageCtxCase("ctx_vit_tiny", tiny_dims(2, vit=True), [5, 9], None, [(56, 84), (112, 70)]),
+    ImageCtxCase("ctx_vae_tiny", tiny_dims(2, vit=True), None, [(64, 96), (128, 64)], None),
+    ImageCtxCase("edit_tiny", tiny_dims(3, vit=True), None, [(128, 96)], [(112, 84)], edit_prompt=[11],
+                 out_image=(128, 96)),
+]}
