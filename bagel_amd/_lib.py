@@ -94,7 +94,7 @@ L = ctypes.c_long
 I = ctypes.c_int
 F = ctypes.c_float
 
-EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU, EPI_BIAS_RESIDUAL, EPI_F32_SCALED = 0, 1, 2, 3, 4
+EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU, EPI_BIAS_RESIDUAL, EPI_F32_SCALED, EPI_BIAS_GELU = 0, 1, 2, 3, 4, 5
 SK_BIAS, SK_RESIDUAL, SK_SWIGLU, SK_BIAS_SILU = 0, 1, 2, 3
 RENORM = {"global": 0, "channel": 1, "text_channel": 2}
 
@@ -144,10 +144,27 @@ def qk_norm_rope_kv(qkv, M, Hq, Hkv, D, qn_first, qn_second, kn_first, kn_second
            "bagel_qk_norm_rope_kv_bf16")
 
 
-def varlen_attention(Q, K_ws, Vt_ws, O, tiles, n_tiles, Hq, Hkv, D, S):
-    _check(lib().bagel_varlen_attention_bf16(_p(Q), _p(K_ws), _p(Vt_ws), _p(O), _p(tiles), I(n_tiles), I(Hq), I(Hkv),
-                                             I(D), L(S), _stream()), "bagel_varlen_attention_bf16")
+def varlen_attention(Q, K_ws, Vt_ws, O, tiles, n_tiles, Hq, Hkv, D, S, softmax_scale=None):
+    if softmax_scale is None:
+        _check(lib().bagel_varlen_attention_bf16(_p(Q), _p(K_ws), _p(Vt_ws), _p(O), _p(tiles), I(n_tiles), I(Hq),
+                                                 I(Hkv), I(D), L(S), _stream()), "bagel_varlen_attention_bf16")
+    else:
+        _check(lib().bagel_varlen_attention_scaled_bf16(_p(Q), _p(K_ws), _p(Vt_ws), _p(O), _p(tiles), I(n_tiles), I(Hq),
+                                                        I(Hkv), I(D), L(S), F(softmax_scale), _stream()),
+               "bagel_varlen_attention_scaled_bf16")
     return O
+
+
+def layernorm(x, out, gamma, beta, eps, rows=None):
+    rows = x.shape[0] if rows is None else rows
+    _check(lib().bagel_layernorm_bf16(_p(x), L(x.stride(0)), _p(out), L(out.stride(0)), I(rows), I(x.shape[1]), _p(gamma),
+                                      _p(beta), F(eps), _stream()), "bagel_layernorm_bf16")
+    return out
+
+
+def split_heads_pad(qkv, M, heads, d_in, d, row_slot, Q, K_ws, Vt_ws, S):
+    _check(lib().bagel_split_heads_pad_bf16(_p(qkv), L(qkv.stride(0)), I(M), I(heads), I(d_in), I(d), _p(row_slot), _p(Q),
+                                            _p(K_ws), _p(Vt_ws), L(S), _stream()), "bagel_split_heads_pad_bf16")
 
 
 def embed_latent(lin, temb, pos_table, pos_id, src_row, X, rows):
@@ -194,9 +211,9 @@ def cfg_euler_update(v_cond, v_text, v_img, cfg_text_scale, cfg_img_scale, renor
 
 
 # ---- FLUX VAE decoder ---------------------------------------------------------------------------
-def conv3x3(x, Hin, Win, Cin, w, bias, out, zero_page, upsample=False, residual=None):
+def conv3x3(x, Hin, Win, Cin, w, bias, out, zero_page, upsample=False, residual=None, downsample=False):
     Cout = w.shape[0]
-    _check(lib().bagel_conv3x3_nhwc_bf16(_p(x), I(Hin), I(Win), I(Cin), I(1 if upsample else 0), _p(w), I(Cout), _p(bias),
+    _check(lib().bagel_conv3x3_nhwc_bf16(_p(x), I(Hin), I(Win), I(Cin), I(2 if downsample else 1 if upsample else 0), _p(w), I(Cout), _p(bias),
                                          _p(residual), _p(out), _p(zero_page), _stream()), "bagel_conv3x3_nhwc_bf16")
     return out
 
@@ -230,6 +247,13 @@ def vae_latent_im2col(z, scale_factor, shift_factor, out):
     _check(lib().bagel_vae_latent_im2col_bf16(_p(z), I(Cz), I(H), I(W), F(scale_factor), F(shift_factor), _p(out),
                                               I(out.shape[1]), _stream()), "bagel_vae_latent_im2col_bf16")
     return out
+
+
+def vae_sample_latent(moments, noise, Cz, H, W, scale_factor, shift_factor, z):
+    _check(lib().bagel_vae_sample_latent_bf16(_p(moments), I(moments.stride(0)), _p(noise), I(Cz), I(H), I(W),
+                                              F(scale_factor), F(shift_factor), _p(z), _stream()),
+           "bagel_vae_sample_latent_bf16")
+    return z
 
 
 def nhwc_to_nchw(x, npix, Cpad, C, out):

@@ -109,8 +109,9 @@ BAGEL_0P5B = BagelDims(hidden_size=896, intermediate_size=4864, num_layers=24,
 
 
 def tiny_vit() -> ViTDims:
-    """Two heads of the real head_dim (72), an intermediate size that is not a multiple of 64 (like 4304)."""
-    return ViTDims(hidden_size=144, intermediate_size=272, num_layers=2, num_heads=2, max_patches_per_side=8)
+    """Eight heads of the real head_dim (72; hidden 576 = 9 x 64), an intermediate size that is not a
+    multiple of 64 (like 4304)."""
+    return ViTDims(hidden_size=576, intermediate_size=272, num_layers=2, num_heads=8, max_patches_per_side=8)
 
 
 def tiny_dims(num_layers: int = 2, vocab_size: int = 512, max_latent_size: int = 64, vit: bool = False) -> BagelDims:

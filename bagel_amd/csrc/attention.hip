@@ -236,10 +236,24 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
   }
 }
 
+extern "C" int bagel_varlen_attention_scaled_bf16(const void* Q, const void* K, const void* Vt, void* O,
+                                                  const void* tiles, int n_tiles, int Hq, int Hkv, int head_dim,
+                                                  long S, float softmax_scale, void* stream);
+
 extern "C" int bagel_varlen_attention_bf16(const void* Q, const void* K, const void* Vt, void* O,
                                            const void* tiles, int n_tiles, int Hq, int Hkv, int head_dim,
                                            long S, void* stream) {
+  return bagel_varlen_attention_scaled_bf16(Q, K, Vt, O, tiles, n_tiles, Hq, Hkv, head_dim, S,
+                                            head_dim > 0 ? 1.0f / sqrtf((float)head_dim) : 0.f, stream);
+}
+
+// Same kernel with the softmax scale given by the caller: heads whose true width is below the kernel's
+// head_dim are zero-padded (SigLIP: 72 -> 128) and keep their own 1/sqrt(72).
+extern "C" int bagel_varlen_attention_scaled_bf16(const void* Q, const void* K, const void* Vt, void* O,
+                                                  const void* tiles, int n_tiles, int Hq, int Hkv, int head_dim,
+                                                  long S, float softmax_scale, void* stream) {
   BAGEL_CHECK(Q && K && Vt && O && tiles, "bagel_varlen_attention_bf16: null operand");
+  BAGEL_CHECK(softmax_scale > 0.f, "bagel_varlen_attention_bf16: softmax scale must be positive");
   BAGEL_CHECK(head_dim == 128 || head_dim == 64, "bagel_varlen_attention_bf16: head_dim %d not supported (128 or 64)", head_dim);
   BAGEL_CHECK(n_tiles > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "bagel_varlen_attention_bf16: bad head counts");
   BAGEL_CHECK(S > 0 && S % 64 == 0, "bagel_varlen_attention_bf16: S=%ld must be a positive multiple of 64", S);
@@ -248,7 +262,7 @@ extern "C" int bagel_varlen_attention_bf16(const void* Q, const void* K, const v
   AttnParams p;
   p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.Vt = (const bf16*)Vt; p.O = (bf16*)O;
   p.tiles = (const AttnTile*)tiles; p.n_tiles = n_tiles; p.Hq = Hq; p.Hkv = Hkv; p.S = S;
-  p.scale_log2 = 1.4426950408889634f / sqrtf((float)head_dim);
+  p.scale_log2 = 1.4426950408889634f * softmax_scale;
   const size_t lds = 2 * (size_t)(KT * head_dim * 2 + head_dim * KT * 2);
   if (head_dim == 128) {
     auto kern = attention_kernel<128>;

@@ -16,6 +16,12 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // round-to-nearest-even f32 -> bf16 -> f32: the value a bf16 store followed by a load would give
 __device__ __forceinline__ float round_bf16(float x) { return (float)(bf16)x; }
 
+// torch GELU(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+__device__ __forceinline__ float gelu_tanh_f32(float x) {
+  const float inner = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.f + tanhf(inner));
+}
+
 __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

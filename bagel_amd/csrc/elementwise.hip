@@ -515,3 +515,119 @@ extern "C" int bagel_argmax_rows_bf16(const void* logits, long ld, int rows, int
   BAGEL_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// nn.LayerNorm (siglip_navit.py:267-269, 343): fp32 statistics and affine on a bf16 row, rounded to bf16
+// once (the consumer is always a bf16 nn.Linear).  One wave per row, values kept in registers.
+// ---------------------------------------------------------------------------------------------
+template <int MAXC>
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__ x, long ldx, bf16* __restrict__ out,
+                                                        long ldo, int rows, int H, const bf16* __restrict__ gamma,
+                                                        const bf16* __restrict__ beta, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int nchunk = H / 8;
+  float v[MAXC][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      const bf16x8 t = *(const bf16x8*)(x + (long)row * ldx + 8 * c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] = (float)t[e];
+        sum += v[i][e];
+      }
+    }
+  }
+  const float mean = wave_sum(sum) / (float)H;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+    if (lane + 64 * i < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[i][e] - mean;
+        sq += d * d;
+      }
+    }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      const bf16x8 g = *(const bf16x8*)(gamma + 8 * c);
+      const bf16x8 b = *(const bf16x8*)(beta + 8 * c);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)((v[i][e] - mean) * rstd * (float)g[e] + (float)b[e]);
+      *(bf16x8*)(out + (long)row * ldo + 8 * c) = o;
+    }
+  }
+}
+
+extern "C" int bagel_layernorm_bf16(const void* x, long ldx, void* out, long ldo, int rows, int H, const void* gamma,
+                                    const void* beta, float eps, void* stream) {
+  BAGEL_CHECK(x && out && gamma && beta, "bagel_layernorm_bf16: null operand");
+  BAGEL_CHECK(rows > 0 && H > 0 && H % 8 == 0 && H <= 4096 && ldx % 8 == 0 && ldo % 8 == 0 && ldx >= H && ldo >= H,
+              "bagel_layernorm_bf16: bad shape rows=%d H=%d", rows, H);
+  const dim3 grid((rows + 3) / 4), block(256);
+#define ARGS (const bf16*)x, ldx, (bf16*)out, ldo, rows, H, (const bf16*)gamma, (const bf16*)beta, eps
+  if (H <= 1536)
+    hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, (hipStream_t)stream, ARGS);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, (hipStream_t)stream, ARGS);
+#undef ARGS
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Plain multi-head attention inputs (no q/k norm, no RoPE: SiglipFlashAttention2 with rope off,
+// siglip_navit.py:216-243) for the attention kernel: qkv [M][3][heads][Din] ->
+//   Q [M][heads][D] , K workspace [heads][S][D] at slot row_slot[row], Vt workspace [heads][D][S],
+// with Din (72 for SigLIP so400m) zero-padded to the kernel's head_dim D.  Zero padding leaves q.k and P.V
+// unchanged; the pad rows of Vt must be zero, which the caller guarantees by zeroing the workspace once.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void split_heads_pad_kernel(const bf16* __restrict__ qkv, long ld, int M, int heads,
+                                                              int Din, int D, const int* __restrict__ row_slot,
+                                                              bf16* __restrict__ Q, bf16* __restrict__ Kws,
+                                                              bf16* __restrict__ Vt, long S) {
+  const int cin = Din / 8, cpd = D / 8;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per_row = (long)heads * cpd;
+  if (idx >= (long)M * per_row) return;
+  const int row = idx / per_row;
+  const int rem = idx % per_row;
+  const int head = rem / cpd, c = rem % cpd;
+  const long slot = row_slot[row];
+  const bf16* src = qkv + (long)row * ld + (long)head * Din + 8 * c;
+  bf16x8 q, k;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) q[e] = k[e] = (bf16)0.f;
+  if (c < cin) {
+    q = *(const bf16x8*)src;
+    k = *(const bf16x8*)(src + (long)heads * Din);
+    const bf16x8 v = *(const bf16x8*)(src + 2L * heads * Din);
+    bf16* dst = Vt + ((long)head * D + 8 * c) * S + slot;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[(long)e * S] = v[e];
+  }
+  *(bf16x8*)(Q + ((long)row * heads + head) * D + 8 * c) = q;
+  *(bf16x8*)(Kws + ((long)head * S + slot) * D + 8 * c) = k;
+}
+
+extern "C" int bagel_split_heads_pad_bf16(const void* qkv, long ld, int M, int heads, int head_dim_in, int head_dim,
+                                          const void* row_slot, void* Q, void* K_ws, void* Vt_ws, long S, void* stream) {
+  BAGEL_CHECK(qkv && row_slot && Q && K_ws && Vt_ws, "bagel_split_heads_pad_bf16: null operand");
+  BAGEL_CHECK(M > 0 && heads > 0 && head_dim_in % 8 == 0 && head_dim % 8 == 0 && head_dim_in <= head_dim,
+              "bagel_split_heads_pad_bf16: bad head dims %d -> %d", head_dim_in, head_dim);
+  BAGEL_CHECK(ld % 8 == 0 && ld >= 3L * heads * head_dim_in, "bagel_split_heads_pad_bf16: bad leading dim");
+  const long n = (long)M * heads * (head_dim / 8);
+  hipLaunchKernelGGL(split_heads_pad_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)qkv, ld, M, heads, head_dim_in, head_dim, (const int*)row_slot, (bf16*)Q, (bf16*)K_ws,
+                     (bf16*)Vt_ws, S);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}

@@ -20,6 +20,7 @@
 //                 with W rows interleaved [16 gate rows | 16 up rows] per 16 features.
 //   EPI_BIAS_RESIDUAL  C = bf16(bf16(acc + bias) + R)         x + conv(x) in the VAE decoder
 //   EPI_F32_SCALED     C (fp32) = alpha * acc                 attention scores of the VAE mid block
+//   EPI_BIAS_GELU      C = bf16(gelu_tanh(bf16(acc + bias)))    SiglipMLP.fc1 / MLPconnector.fc1 + activation
 #include "gemm_tile.h"
 #include "gemm_pingpong.h"
 #include "gemm_pipelined.h"
@@ -48,6 +49,7 @@ static int launch_gemm(GemmParams p, int epilogue, hipStream_t stream) {
     case EPI_SWIGLU: LAUNCH(EPI_SWIGLU); break;
     case EPI_BIAS_RESIDUAL: LAUNCH(EPI_BIAS_RESIDUAL); break;
     case EPI_F32_SCALED: LAUNCH(EPI_F32_SCALED); break;
+    case EPI_BIAS_GELU: LAUNCH(EPI_BIAS_GELU); break;
     default: bagel_set_error("bagel_gemm_bf16: unknown epilogue %d", epilogue); return 1;
   }
 #undef LAUNCH
@@ -76,6 +78,7 @@ static int launch_pingpong(GemmParams p, int epilogue, hipStream_t stream) {
     case EPI_SWIGLU: LAUNCH(EPI_SWIGLU); break;
     case EPI_BIAS_RESIDUAL: LAUNCH(EPI_BIAS_RESIDUAL); break;
     case EPI_F32_SCALED: LAUNCH(EPI_F32_SCALED); break;
+    case EPI_BIAS_GELU: LAUNCH(EPI_BIAS_GELU); break;
     default: bagel_set_error("bagel_gemm_bf16: unknown epilogue %d", epilogue); return 1;
   }
 #undef LAUNCH
@@ -113,6 +116,7 @@ static int launch_pipelined(GemmParams p, int epilogue, hipStream_t stream) {
       }
     case EPI_BIAS_RESIDUAL: LAUNCH(EPI_BIAS_RESIDUAL); break;
     case EPI_F32_SCALED: LAUNCH(EPI_F32_SCALED); break;
+    case EPI_BIAS_GELU: LAUNCH(EPI_BIAS_GELU); break;
     default: bagel_set_error("bagel_gemm_bf16: unknown epilogue %d", epilogue); return 1;
   }
 #undef LAUNCH
@@ -154,7 +158,7 @@ extern "C" int bagel_gemm_bf16(const void* A, long lda, const void* W, long ldw,
   BAGEL_CHECK(((uintptr_t)A | (uintptr_t)W) % 16 == 0 && (uintptr_t)C % 8 == 0, "bagel_gemm_bf16: misaligned operand");
   if (epilogue == EPI_RESIDUAL || epilogue == EPI_BIAS_RESIDUAL)
     BAGEL_CHECK(residual && ldr % 4 == 0 && (uintptr_t)residual % 8 == 0, "bagel_gemm_bf16: residual epilogue needs R");
-  if (epilogue == EPI_BIAS_RESIDUAL) BAGEL_CHECK(bias, "bagel_gemm_bf16: bias+residual epilogue needs bias");
+  if (epilogue == EPI_BIAS_RESIDUAL || epilogue == EPI_BIAS_GELU) BAGEL_CHECK(bias, "bagel_gemm_bf16: this epilogue needs bias");
   if (epilogue == EPI_F32_SCALED) BAGEL_CHECK((uintptr_t)C % 16 == 0, "bagel_gemm_bf16: fp32 output must be 16-byte aligned");
   if (epilogue == EPI_SWIGLU) BAGEL_CHECK(N % 32 == 0, "bagel_gemm_bf16: swiglu needs N %% 32 == 0");
   if (bias) BAGEL_CHECK((uintptr_t)bias % 8 == 0, "bagel_gemm_bf16: misaligned bias");

@@ -3,7 +3,7 @@
 #pragma once
 #include "common.h"
 
-enum { EPI_BIAS = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_BIAS_RESIDUAL = 3, EPI_F32_SCALED = 4 };
+enum { EPI_BIAS = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_BIAS_RESIDUAL = 3, EPI_F32_SCALED = 4, EPI_BIAS_GELU = 5 };
 enum { A_DENSE = 0, A_CONV3X3 = 1 };
 
 struct GemmParams {
@@ -16,7 +16,8 @@ struct GemmParams {
   int tiles_m, tiles_n;
   float alpha;                 // EPI_F32_SCALED: C (fp32) = alpha * acc
   // A_CONV3X3: A is an NHWC image [Hin][Win][Cin]; row m of the GEMM is output pixel (m / Wout, m % Wout),
-  // K runs over (ky, kx, c); taps outside the (optionally 2x nearest-upsampled) image read `zeros`.
+  // K runs over (ky, kx, c); taps outside the image read `zeros`.  upsample: 0 = stride 1, padding 1;
+  // 1 = the same on the 2x nearest-upsampled input; 2 = stride 2 with one zero row/column on the bottom/right.
   int Hout, Wout, Hin, Win, Cin, upsample;
   const bf16* zeros;
 };
@@ -89,6 +90,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
           const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (bf16)(round_bf16(acc[i][j][r] + (float)b4[r]) + (float)r4[r]);
+        } else if constexpr (EPI == EPI_BIAS_GELU) {
+          const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16)gelu_tanh_f32(round_bf16(acc[i][j][r] + (float)b4[r]));
         } else {
           if (p.bias != nullptr) {
             const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
@@ -168,10 +173,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmParams p)
         src = a_src[it] + koff;
       } else {
         int y = a_oy[it] + tap_dy, x = a_ox[it] + tap_dx;
-        const bool ok = y >= 0 && y < p.Hout && x >= 0 && x < p.Wout;
-        if (p.upsample) {
+        bool ok = y >= 0 && y < p.Hout && x >= 0 && x < p.Wout;
+        if (p.upsample == 1) {
           y >>= 1;
           x >>= 1;
+        } else if (p.upsample == 2) {
+          y = 2 * a_oy[it] + tap_dy + 1;
+          x = 2 * a_ox[it] + tap_dx + 1;
+          ok = y < p.Hin && x < p.Win;
         }
         src = ok ? a_src[it] + ((long)y * p.Win + x) * p.Cin + c0 : p.zeros + src_chunk * 8;
       }

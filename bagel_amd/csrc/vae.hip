@@ -10,8 +10,10 @@
 #include "gemm_tile.h"
 
 // -------------------------------------------------------------------------------------------------
-// conv3x3, stride 1, padding 1, optional fused nearest-2x upsample of the input.
-// nn.Conv2d calls at autoencoder.py:76,78 (ResnetBlock), :114 (Upsample), :248 (conv_out).
+// conv3x3: stride 1, padding 1 (resample mode 0); the same on the nearest-2x upsampled input (mode 1);
+// stride 2 after padding one zero row/column on the bottom/right (mode 2; Downsample.forward,
+// autoencoder.py:98-108).
+// nn.Conv2d calls at autoencoder.py:76,78 (ResnetBlock), :102, :114 (Upsample), :170, :248 (conv_out).
 // W is pre-arranged [Cout][ky][kx][Cin]; Cin % 64 == 0.
 // -------------------------------------------------------------------------------------------------
 extern "C" int bagel_conv3x3_nhwc_bf16(const void* x, int Hin, int Win, int Cin, int upsample, const void* w, int Cout,
@@ -20,10 +22,12 @@ extern "C" int bagel_conv3x3_nhwc_bf16(const void* x, int Hin, int Win, int Cin,
   BAGEL_CHECK(x && w && bias && out && zero_page, "bagel_conv3x3_nhwc_bf16: null operand");
   BAGEL_CHECK(Cin % 64 == 0 && Cout % 4 == 0, "bagel_conv3x3_nhwc_bf16: Cin=%d must be a multiple of 64, Cout=%d of 4", Cin, Cout);
   BAGEL_CHECK(Hin > 0 && Win > 0, "bagel_conv3x3_nhwc_bf16: empty image");
+  BAGEL_CHECK(upsample >= 0 && upsample <= 2, "bagel_conv3x3_nhwc_bf16: resample mode %d unknown", upsample);
+  BAGEL_CHECK(upsample != 2 || (Hin % 2 == 0 && Win % 2 == 0), "bagel_conv3x3_nhwc_bf16: stride 2 needs even %dx%d", Hin, Win);
   GemmParams p;
-  p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.upsample = upsample ? 1 : 0;
-  p.Hout = upsample ? 2 * Hin : Hin;
-  p.Wout = upsample ? 2 * Win : Win;
+  p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.upsample = upsample;
+  p.Hout = upsample == 1 ? 2 * Hin : upsample == 2 ? Hin / 2 : Hin;
+  p.Wout = upsample == 1 ? 2 * Win : upsample == 2 ? Win / 2 : Win;
   p.A = (const bf16*)x; p.lda = Cin;
   p.W = (const bf16*)w; p.ldw = 9L * Cin;
   p.C = (bf16*)out; p.ldc = Cout;
@@ -270,6 +274,36 @@ extern "C" int bagel_nhwc_to_nchw_bf16(const void* in, long npix, int Cpad, int 
   const long n = npix * C;
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)in,
                      npix, Cpad, C, (bf16*)out);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Encoder output -> latent: DiagonalGaussian + scale/shift (autoencoder.py:281-287, 315-318) on the bf16
+// moments the encoder's conv_out produced; every elementwise op rounds to bf16 as it does on a bf16 tensor.
+// moments NHWC [H*W][ldm] (mean channels 0..Cz-1, logvar Cz..2Cz-1), noise and z NCHW bf16.
+// -------------------------------------------------------------------------------------------------
+__global__ void vae_sample_latent_kernel(const bf16* __restrict__ mom, int ldm, const bf16* __restrict__ noise, int Cz,
+                                         long npix, float scale, float shift, bf16* __restrict__ z) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= npix * Cz) return;
+  const int c = idx / npix;
+  const long pix = idx % npix;
+  const float mean = (float)mom[pix * ldm + c];
+  const float logvar = (float)mom[pix * ldm + Cz + c];
+  const float std = round_bf16(__expf(round_bf16(0.5f * logvar)));
+  const float v = round_bf16(mean + round_bf16(std * (float)noise[idx]));
+  z[idx] = (bf16)(scale * round_bf16(v - shift));
+}
+
+extern "C" int bagel_vae_sample_latent_bf16(const void* moments_nhwc, int ldm, const void* noise_nchw, int Cz, int H,
+                                            int W, float scale_factor, float shift_factor, void* z_nchw, void* stream) {
+  BAGEL_CHECK(moments_nhwc && noise_nchw && z_nchw && Cz > 0 && ldm >= 2 * Cz && H > 0 && W > 0,
+              "bagel_vae_sample_latent_bf16: bad arguments");
+  const long n = (long)H * W * Cz;
+  hipLaunchKernelGGL(vae_sample_latent_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)moments_nhwc, ldm, (const bf16*)noise_nchw, Cz, (long)H * W, scale_factor, shift_factor,
+                     (bf16*)z_nchw);
   BAGEL_LAUNCH_CHECK();
   return 0;
 }

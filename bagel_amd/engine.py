@@ -315,6 +315,20 @@ class MoTEngine:
         K.gemm(Xn, w.l2v_w, Vout, bias=w.l2v_b, M=Mv)
         return Vout
 
+    def extract_gen_kv(self, plan: GenPlan):
+        """After forward_gen: per layer the merged keys/values ``[sum(ctx + n + 2), Hkv, D]`` of the plan's units
+        in the reference's order [context | start_of_image | latent tokens | end_of_image] per sample
+        (the workspace keeps the two text rows after the latent rows)."""
+        L = self.dims.num_layers
+        order = []
+        for u, n, ks in zip(plan.units, plan.nv, plan.kv_start):
+            c = u.ctx_len
+            order += list(range(ks, ks + c)) + [ks + c + n] + list(range(ks + c, ks + c + n)) + [ks + c + n + 1]
+        idx = torch.tensor(order, dtype=torch.long, device=self.device)
+        keys = [self.kws[l].index_select(1, idx).permute(1, 0, 2).contiguous() for l in range(L)]
+        values = [self.vtws[l].index_select(2, idx).permute(2, 0, 1).contiguous() for l in range(L)]
+        return keys, values
+
     # ---- understanding-mode prefill (context KV build) ------------------------------------------
     def _linear_und(self, x, w, out, bias=None, residual=None, kind="bias"):
         """x [M, K] through one understanding-expert projection: weight-streaming path for M <= 64 rows,
@@ -330,12 +344,13 @@ class MoTEngine:
 
     def prefill_und(self, emb: torch.Tensor, lens: Sequence[int], pos0: Sequence[int], ctx_lens: Sequence[int],
                     ctx_k: Sequence[Optional[List[torch.Tensor]]], ctx_v: Sequence[Optional[List[torch.Tensor]]],
-                    is_causal: bool = True):
+                    is_causal: bool = True, same_position: bool = False):
         """Qwen2Model.forward_inference(mode="und", update_past_key_values=True) for packed text tokens
         (qwen2_navit.py:1041-1115 via bagel.py:844-874): returns per layer the merged keys and values
         ``[sum(ctx + new), Hkv, D]`` in sample order, i.e. the tensors NaiveCache holds afterwards.
         Sample b contributes ``lens[b]`` new tokens at RoPE positions pos0[b].. after ``ctx_lens[b]``
-        context tokens.  The last layer's attention and MLP are skipped: only keys/values are kept."""
+        context tokens (``same_position``: all of a sample's tokens share position pos0[b], as the tokens of
+        one image do, bagel.py:917).  The last layer's attention and MLP are skipped: only keys/values are kept."""
         d, w = self.dims, self.w
         H, I, Hq, Hkv, D = d.hidden_size, d.intermediate_size, d.num_heads, d.num_kv_heads, d.head_dim
         M = int(sum(lens))
@@ -360,7 +375,7 @@ class MoTEngine:
                 for l in range(L):
                     kws[l, :, ks:ks + c, :].copy_(ctx_k[b][l].permute(1, 0, 2))
                     vtws[l, :, :, ks:ks + c].copy_(ctx_v[b][l].permute(1, 2, 0))
-            positions += list(range(pos0[b], pos0[b] + n))
+            positions += [pos0[b]] * n if same_position else list(range(pos0[b], pos0[b] + n))
             row_slot += list(range(ks + c, ks + c + n))
             for q0 in range(0, n, 128):
                 tiles.append((row0[b] + q0, min(128, n - q0), ks, c + n, (c + q0) if is_causal else -1, 0, 0, 0))

@@ -4,7 +4,8 @@ HIP-backed ``Bagel`` and ``AutoEncoder``.  Same constructor, same method names, 
 Covered: text prompts -> image (``interleave_inference`` / ``__call__`` with ``text=...``), ``gen_image``,
 ``decode_image``, context bookkeeping with ``deepcopy`` snapshots for the CFG branches.
 ``gen_text`` and the think modes (autoregressive decoding through the understanding expert) are covered too.
-Not covered yet (raise NotImplementedError): image inputs (VAE encode + SigLIP prefill).
+Image inputs (``update_context_image``: VAE encode + VAE-token prefill, SigLIP tower + connector prefill) are
+covered as well; the image transforms are host code in ``bagel_amd/transforms.py``.
 """
 from __future__ import annotations
 
@@ -14,6 +15,7 @@ from typing import List, Union
 import torch
 from PIL import Image
 
+from .transforms import pil_img2rgb
 from .modeling.bagel import NaiveCache
 
 
@@ -53,8 +55,26 @@ class InterleaveInferencer:
         gen_context["past_key_values"] = past_key_values
         return gen_context
 
+    @torch.no_grad()
     def update_context_image(self, image, gen_context, vae=True, vit=True):
-        raise NotImplementedError("image inputs (VAE encode + SigLIP prefill, inferencer.py:79-123) are not implemented")
+        """inferencer.py:79-123: append the image's VAE tokens and / or ViT tokens to the context."""
+        assert vae or vit
+        past_key_values = gen_context["past_key_values"]
+        kv_lens, ropes = gen_context["kv_lens"], gen_context["ropes"]
+        if vae:
+            generation_input, kv_lens, ropes = self.model.prepare_vae_images(
+                curr_kvlens=kv_lens, curr_rope=ropes, images=[image], transforms=self.vae_transform,
+                new_token_ids=self.new_token_ids)
+            past_key_values = self.model.forward_cache_update_vae(self.vae_model, past_key_values, **generation_input)
+        if vit:
+            generation_input, kv_lens, ropes = self.model.prepare_vit_images(
+                curr_kvlens=kv_lens, curr_rope=ropes, images=[image], transforms=self.vit_transform,
+                new_token_ids=self.new_token_ids)
+            past_key_values = self.model.forward_cache_update_vit(past_key_values, **generation_input)
+        gen_context["kv_lens"] = kv_lens
+        gen_context["ropes"] = ropes
+        gen_context["past_key_values"] = past_key_values
+        return gen_context
 
     @torch.no_grad()
     def gen_image(self, image_shape, gen_context, cfg_text_scale=4.0, cfg_img_scale=1.5, cfg_text_precontext=None,
@@ -134,7 +154,10 @@ class InterleaveInferencer:
                 gen_context = self.update_context_text(input_term, gen_context)
                 cfg_img_context = self.update_context_text(input_term, cfg_img_context)
             elif isinstance(input_term, Image.Image):
-                gen_context = self.update_context_image(input_term, gen_context)
+                input_term = self.vae_transform.resize_transform(pil_img2rgb(input_term))
+                gen_context = self.update_context_image(input_term, gen_context, vae=not understanding_output)
+                image_shapes = input_term.size[::-1]
+                cfg_text_context = deepcopy(gen_context)
             else:
                 raise ValueError(f"Unsupported input type: {type(input_term)}")
         if understanding_output:

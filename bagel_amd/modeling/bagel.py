@@ -72,6 +72,13 @@ class Bagel:
                 raise ValueError("Bagel needs a state dict (reference parameter names) or prepared MoTWeights")
             weights = MoTWeights.from_state_dict(dims, state_dict, self.device)
         self.engine = MoTEngine(dims, weights, self.device)
+        self.vit_tower = None
+        if dims.vit is not None and state_dict is not None and "connector.fc1.weight" in state_dict:
+            from .siglip import SiglipTower
+            self.vit_tower = SiglipTower(dims.vit, dims.hidden_size, state_dict, self.device)
+            self.vit_patch_size = dims.vit.patch_size
+            self.vit_max_num_patch_per_side = dims.vit.max_patches_per_side
+            self.vit_hidden_size = dims.vit.hidden_size
         self.config = _Config(dims)
         self.hidden_size = dims.hidden_size
         self.use_moe = True
@@ -156,6 +163,183 @@ class Bagel:
         keys, values = self.engine.prefill_und(emb, lens, pos0, kvl, ctx_k, ctx_v, is_causal=True)
         # like the reference, the given cache object is updated and returned (qwen2_navit.py:607-609)
         for l in range(L):
+            past_key_values.key_cache[l] = keys[l]
+            past_key_values.value_cache[l] = values[l]
+        return past_key_values
+
+    # ------------------------------------------------------------------------------------------
+    # image inputs: ViT tokens (understanding) and VAE tokens (generation expert) into the context
+    # ------------------------------------------------------------------------------------------
+    def _prepare_image_tokens(self, curr_kvlens, curr_rope, token_counts, new_token_ids):
+        """Index lists shared by prepare_vit_images and prepare_vae_images (bagel.py:883-920, 1017-1058):
+        per sample [start_of_image, image tokens, end_of_image], all at the sample's current RoPE position."""
+        img_idx, text_ids, text_idx, seqlens, pos_ids, idx, kvidx = [], [], [], [], [], [], []
+        _curr = curr = 0
+        newlens, new_rope = [], []
+        for n, kvlen, rope in zip(token_counts, curr_kvlens, curr_rope):
+            kvidx.extend(range(curr, curr + kvlen))
+            curr += kvlen
+            text_ids.append(new_token_ids["start_of_image"])
+            text_idx.append(_curr)
+            idx.append(curr)
+            curr += 1
+            _curr += 1
+            img_idx.extend(range(_curr, _curr + n))
+            idx.extend(range(curr, curr + n))
+            curr += n
+            _curr += n
+            text_ids.append(new_token_ids["end_of_image"])
+            text_idx.append(_curr)
+            idx.append(curr)
+            curr += 1
+            _curr += 1
+            pos_ids.extend([rope] * (n + 2))
+            seqlens.append(n + 2)
+            newlens.append(kvlen + n + 2)
+            new_rope.append(rope + 1)
+        gi = {
+            "packed_text_ids": torch.tensor(text_ids, dtype=torch.long),
+            "packed_text_indexes": torch.tensor(text_idx, dtype=torch.long),
+            "packed_position_ids": torch.tensor(pos_ids, dtype=torch.long),
+            "packed_seqlens": torch.tensor(seqlens, dtype=torch.int),
+            "packed_indexes": torch.tensor(idx, dtype=torch.long),
+            "packed_key_value_indexes": torch.tensor(kvidx, dtype=torch.long),
+            "key_values_lens": torch.tensor(curr_kvlens, dtype=torch.int),
+        }
+        return gi, img_idx, newlens, new_rope
+
+    def _image_context(self, past_key_values, packed_seqlens, packed_position_ids, packed_indexes, key_values_lens,
+                       packed_key_value_indexes, packed_text_indexes, image_token_indexes):
+        """Validate the [soi, image tokens, eoi] per-sample layout and slice the context per sample."""
+        cpu = lambda t: t.detach().cpu()  # noqa: E731
+        seqlens = [int(x) for x in cpu(packed_seqlens).tolist()]
+        self._check_packing(seqlens, cpu(packed_text_indexes), cpu(image_token_indexes))
+        return seqlens, self._branch_units(0, seqlens, cpu(packed_position_ids), cpu(packed_indexes), past_key_values,
+                                           cpu(key_values_lens), cpu(packed_key_value_indexes))
+
+    def prepare_vit_images(self, curr_kvlens, curr_rope, images, transforms, new_token_ids):
+        """bagel.py:876-936."""
+        if self.dims.vit is None:
+            raise ValueError("this model was built without a vision tower (dims.vit is None)")
+        vit = self.dims.vit
+        toks, pos = [], []
+        for image in images:
+            t = transforms(image)
+            pos.append(self.get_flattened_position_ids(t.size(1), t.size(2), vit.patch_size,
+                                                       max_num_patches_per_side=vit.max_patches_per_side))
+            c, h, w = t.shape
+            assert h % vit.patch_size == 0 and w % vit.patch_size == 0
+            q = vit.patch_size
+            toks.append(torch.einsum("chpwq->hwpqc", t.reshape(c, h // q, q, w // q, q)).reshape(-1, q * q * c))
+        gi, img_idx, newlens, new_rope = self._prepare_image_tokens(curr_kvlens, curr_rope, [t.shape[0] for t in toks],
+                                                                    new_token_ids)
+        gi.update({
+            "vit_token_seqlens": torch.tensor([t.shape[0] for t in toks], dtype=torch.int),
+            "packed_vit_tokens": torch.cat(toks, dim=0),
+            "packed_vit_position_ids": torch.cat(pos, dim=0),
+            "packed_vit_token_indexes": torch.tensor(img_idx, dtype=torch.long),
+        })
+        return gi, newlens, new_rope
+
+    @torch.no_grad()
+    def forward_cache_update_vit(self, past_key_values: NaiveCache, packed_text_ids, packed_text_indexes,
+                                 packed_vit_tokens, packed_vit_token_indexes, packed_vit_position_ids, vit_token_seqlens,
+                                 packed_position_ids, packed_seqlens, packed_indexes, packed_key_value_indexes,
+                                 key_values_lens):
+        """bagel.py:938-1008: SigLIP tower + connector, then a non-causal understanding-mode prefill of
+        [start_of_image, ViT tokens, end_of_image] per sample.  Updates and returns the cache."""
+        if self.vit_tower is None:
+            raise ValueError("this model was built without vision-tower weights")
+        if vit_token_seqlens is None or len(vit_token_seqlens) == 0:
+            raise ValueError("vit_token_seqlens must hold one length per image")
+        if int(torch.min(vit_token_seqlens)) < 0:
+            raise ValueError(f"vit_token_seqlens holds a negative length: {vit_token_seqlens}")
+        seqlens, units = self._image_context(past_key_values, packed_seqlens, packed_position_ids, packed_indexes,
+                                             key_values_lens, packed_key_value_indexes, packed_text_indexes,
+                                             packed_vit_token_indexes)
+        dev, H = self.device, self.dims.hidden_size
+        ve = self.vit_tower.embed(packed_vit_tokens, packed_vit_position_ids, vit_token_seqlens.tolist())
+        ids = packed_text_ids.detach().cpu().to(torch.int32).to(dev)
+        te = torch.empty((ids.numel(), H), device=dev, dtype=BF16)
+        K.gather_rows(self.engine.w.embed_tokens, ids, te, ids.numel())
+        M = sum(seqlens)
+        seq = torch.empty((M, H), device=dev, dtype=BF16)
+        seq[packed_text_indexes.to(dev)] = te
+        seq[packed_vit_token_indexes.to(dev)] = ve
+        keys, values = self.engine.prefill_und(seq, seqlens, [u.rope_pos for u in units], [u.ctx_len for u in units],
+                                               [u.ctx_k for u in units], [u.ctx_v for u in units], is_causal=False,
+                                               same_position=True)
+        for l in range(self.dims.num_layers):
+            past_key_values.key_cache[l] = keys[l]
+            past_key_values.value_cache[l] = values[l]
+        return past_key_values
+
+    def prepare_vae_images(self, curr_kvlens, curr_rope, images, transforms, new_token_ids, timestep=0):
+        """bagel.py:1010-1081."""
+        ds = self.latent_downsample
+        tensors = [transforms(image) for image in images]
+        shapes = [(t.shape[1] // ds, t.shape[2] // ds) for t in tensors]
+        pos = [self.get_flattened_position_ids(t.size(1), t.size(2), ds, max_num_patches_per_side=self.max_latent_size)
+               for t in tensors]
+        gi, img_idx, newlens, new_rope = self._prepare_image_tokens(curr_kvlens, curr_rope, [h * w for h, w in shapes],
+                                                                    new_token_ids)
+        size = [max(s) for s in zip(*[t.shape for t in tensors])]
+        padded = torch.zeros(size=(len(tensors), *size))
+        for i, t in enumerate(tensors):
+            padded[i, :, :t.shape[1], :t.shape[2]] = t
+        gi.update({
+            "padded_images": padded,
+            "patchified_vae_latent_shapes": shapes,
+            "packed_vae_position_ids": torch.cat(pos, dim=0),
+            "packed_timesteps": torch.tensor([timestep]),
+            "packed_vae_token_indexes": torch.tensor(img_idx, dtype=torch.long),
+        })
+        return gi, newlens, new_rope
+
+    @torch.no_grad()
+    def forward_cache_update_vae(self, vae_model, past_key_values: NaiveCache, padded_images, patchified_vae_latent_shapes,
+                                 packed_vae_position_ids, packed_timesteps, packed_vae_token_indexes, packed_text_ids,
+                                 packed_text_indexes, packed_position_ids, packed_seqlens, packed_indexes, key_values_lens,
+                                 packed_key_value_indexes, latent_noise: Optional[torch.Tensor] = None):
+        """bagel.py:1083-1143: VAE-encode the images, embed the latent patches (vae2llm + t_emb + pos) and
+        prefill them through the generation expert (non-causal; start/end tokens through the understanding
+        expert).  ``latent_noise`` (not in the reference) fixes the Gaussian draw of the VAE posterior, which
+        the reference takes from the device RNG.  Updates and returns the cache."""
+        cpu = lambda t: t.detach().cpu()  # noqa: E731
+        eng, d, dev = self.engine, self.dims, self.device
+        seqlens, units = self._image_context(past_key_values, packed_seqlens, packed_position_ids, packed_indexes,
+                                             key_values_lens, packed_key_value_indexes, packed_text_indexes,
+                                             packed_vae_token_indexes)
+        tt = cpu(packed_timesteps)
+        if tt.numel() != 1:
+            raise NotImplementedError("one timestep for all VAE tokens is supported (prepare_vae_images passes one)")
+        if not tt.dtype.is_floating_point and int(tt[0]) != 0:
+            # modeling_utils.py:98-103 casts the frequency table to the timestep's dtype: an integer timestep
+            # truncates the table to [1, 0, 0, ...]; only 0 (what every caller passes) is meaningful
+            raise NotImplementedError("integer timesteps other than 0 are not supported")
+        padded_latent = vae_model.encode(padded_images, noise=latent_noise)
+        q, c = self.latent_patch_size, self.latent_channel
+        packed = []
+        for latent, (h, w) in zip(padded_latent, patchified_vae_latent_shapes):
+            latent = latent[:, :h * q, :w * q].reshape(c, h, q, w, q)
+            packed.append(torch.einsum("chpwq->hwpqc", latent).reshape(-1, q * q * c))
+        packed = torch.cat(packed, dim=0).to(BF16).contiguous()
+        sample_nv = [n - 2 for n in seqlens]
+        if packed.shape[0] != sum(sample_nv):
+            raise ValueError("patchified_vae_latent_shapes do not match packed_seqlens")
+        sample_row0 = [sum(sample_nv[:b]) for b in range(len(seqlens))]
+        plan = eng.build_plan(units, sample_nv, sample_row0)
+        eng.load_context(plan)
+        for u in units:
+            u.ctx_k = u.ctx_v = None
+        eng.set_latent_position_ids(cpu(packed_vae_position_ids))
+        ids = cpu(packed_text_ids).to(torch.int32).to(dev)
+        text_emb = torch.empty((plan.Mt, d.hidden_size), device=dev, dtype=BF16)
+        K.gather_rows(eng.w.embed_tokens, ids, text_emb, plan.Mt)
+        temb = eng.timestep_table(tt.float())
+        eng.forward_gen(plan, packed, temb[0], text_emb)
+        keys, values = eng.extract_gen_kv(plan)
+        for l in range(d.num_layers):
             past_key_values.key_cache[l] = keys[l]
             past_key_values.value_cache[l] = values[l]
         return past_key_values

@@ -25,6 +25,8 @@ const char* bagel_last_error(void);
                                 [16 gate rows | 16 up rows] per 16 features; C has N/2 columns */
 #define BAGEL_EPI_BIAS_RESIDUAL 3 /* C = bf16(bf16(acc + bias) + R) */
 #define BAGEL_EPI_F32_SCALED 4    /* C is fp32: C = alpha * acc */
+#define BAGEL_EPI_BIAS_GELU 5     /* C = bf16(gelu_tanh(bf16(acc + bias))): SiglipMLP.fc1 + activation
+                                     (siglip_navit.py:255-258), MLPconnector.fc1 (modeling_utils.py:122-125) */
 
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T), bf16 operands, fp32 accumulation on the MFMA units.
  * Replaces the nn.Linear calls of the generation expert: q/k/v_proj_moe_gen (qwen2_navit.py:541-547),
@@ -77,6 +79,25 @@ int bagel_qk_norm_rope_kv_bf16(const void* qkv, long ld, int M, int Hq, int Hkv,
 int bagel_varlen_attention_bf16(const void* Q, const void* K_ws, const void* Vt_ws, void* O, const void* tiles,
                                 int n_tiles, int Hq, int Hkv, int head_dim, long S, void* stream);
 
+/* The same kernel with the softmax scale given by the caller (bagel_varlen_attention_bf16 uses
+ * 1/sqrt(head_dim)): for heads narrower than the kernel's head_dim that were zero-padded, e.g. the 72-wide
+ * heads of flash_attn_varlen_func at siglip_navit.py:232-241. */
+int bagel_varlen_attention_scaled_bf16(const void* Q, const void* K_ws, const void* Vt_ws, void* O, const void* tiles,
+                                       int n_tiles, int Hq, int Hkv, int head_dim, long S, float softmax_scale,
+                                       void* stream);
+
+/* nn.LayerNorm with fp32 statistics on bf16 rows (H % 8 == 0, H <= 4096), bf16 affine:
+ * siglip_navit.py:267-269, 283, 296, 343, 370. */
+int bagel_layernorm_bf16(const void* x, long ldx, void* out, long ldo, int rows, int H, const void* gamma,
+                         const void* beta, float eps, void* stream);
+
+/* qkv [M][3][heads][head_dim_in] -> Q [M][heads][head_dim], K_ws [heads][S][head_dim] and Vt_ws
+ * [heads][head_dim][S] at slot row_slot[row], zero-padding head_dim_in up to head_dim (no q/k norm, no
+ * RoPE): the reshapes of SiglipFlashAttention2.forward, siglip_navit.py:216-222.  The pad rows of Vt_ws are
+ * not written: zero the workspace once. */
+int bagel_split_heads_pad_bf16(const void* qkv, long ld, int M, int heads, int head_dim_in, int head_dim,
+                               const void* row_slot, void* Q, void* K_ws, void* Vt_ws, long S, void* stream);
+
 /* X[r] = bf16(bf16(lin[src_row[r]] + temb) + pos_table[pos_id[src_row[r]]]): bagel.py:1394-1399. */
 int bagel_embed_latent_bf16(const void* lin, long ldl, const void* temb, const void* pos_table, const void* pos_id,
                             const void* src_row, void* X, long ldx, int rows, int H, void* stream);
@@ -104,12 +125,14 @@ int bagel_cfg_euler_update(const void* v_cond, const void* v_text, const void* v
 
 /* ---- FLUX VAE decoder (modeling/autoencoder.py:196-272, 320-322); activations are NHWC bf16 ---- */
 
-/* 3x3 convolution, stride 1, padding 1, as an implicit GEMM on the MFMA units; `upsample` != 0 first
- * applies nearest-neighbour 2x upsampling to x (Upsample.forward, autoencoder.py:116-119).
+/* 3x3 convolution as an implicit GEMM on the MFMA units.  `upsample` selects the resampling fused into the
+ * input gather: 0 = stride 1, padding 1; 1 = the same after nearest-neighbour 2x upsampling of x
+ * (Upsample.forward, autoencoder.py:116-119); 2 = stride 2 after one zero row/column of padding on the
+ * bottom/right (Downsample.forward, autoencoder.py:104-108; Hout = Hin / 2).
  *   x [Hin][Win][Cin], w [Cout][3][3][Cin], bias [Cout], residual/out [Hout*Wout][Cout]
  *   out = bf16(acc + bias), or bf16(bf16(acc + bias) + residual) when residual != NULL
  *   zero_page: >= 128 zero bytes of device memory (source of the padding taps).
- * Replaces nn.Conv2d at autoencoder.py:76,78,114,248 and the `x + h` of ResnetBlock (:95). */
+ * Replaces nn.Conv2d at autoencoder.py:76,78,102,114,170,248 and the `x + h` of ResnetBlock (:95). */
 int bagel_conv3x3_nhwc_bf16(const void* x, int Hin, int Win, int Cin, int upsample, const void* w, int Cout,
                             const void* bias, const void* residual, void* out, const void* zero_page, void* stream);
 
@@ -130,6 +153,12 @@ int bagel_transpose_bf16(const void* in, int R, int C, void* out, void* stream);
  * z is NCHW fp32, K order (ky, kx, c), zero padded to Kpad (multiple of 64). */
 int bagel_vae_latent_im2col_bf16(const void* z_nchw_f32, int Cz, int H, int W, float scale_factor, float shift_factor,
                                  void* out, int Kpad, void* stream);
+
+/* z = scale * ((mean + exp(0.5 logvar) * noise) - shift), bf16 with a rounding after every elementwise op:
+ * DiagonalGaussian.forward + AutoEncoder.encode (autoencoder.py:281-287, 315-318).
+ *   moments NHWC [H*W][ldm] bf16 (mean | logvar channels), noise and z NCHW [Cz][H][W] bf16. */
+int bagel_vae_sample_latent_bf16(const void* moments_nhwc, int ldm, const void* noise_nchw, int Cz, int H, int W,
+                                 float scale_factor, float shift_factor, void* z_nchw, void* stream);
 
 /* NHWC bf16 (Cpad channels) -> NCHW bf16 (first C channels). */
 int bagel_nhwc_to_nchw_bf16(const void* in, long npix, int Cpad, int C, void* out, void* stream);
