@@ -9,8 +9,10 @@
 // Qwen2RMSNorm.forward (modeling_qwen2.py:54-59): fp32 statistics, normalised value rounded to bf16,
 // then multiplied by the bf16 weight and rounded again.  Per-modality weights:
 // Qwen2MoTDecoderLayer.forward_inference (qwen2_navit.py:798-800, 826-829), final norm (:1102-1104).
-// One wave per row; the second pass re-reads the row from cache.
+// One wave per row.  Rows of up to 4096 elements stay in registers between the two passes (one HBM read,
+// one write); wider rows are read a second time.
 // ---------------------------------------------------------------------------------------------
+template <int MAXC>  // 16-byte chunks per lane held in registers; 0 = re-read the row
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16* __restrict__ x, long ldx, bf16* __restrict__ out,
                                                       long ldo, int rows, int H, const bf16* __restrict__ w_first,
                                                       const bf16* __restrict__ w_second, int split, float eps) {
@@ -19,22 +21,48 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16* __restrict__ x
   const int lane = threadIdx.x & 63;
   const bf16* xr = x + (long)row * ldx;
   const bf16* w = row < split ? w_first : w_second;
-  float ss = 0.f;
-  for (int c = lane * 8; c < H; c += 512) {
-    const bf16x8 v = *(const bf16x8*)(xr + c);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ss += (float)v[j] * (float)v[j];
-  }
-  ss = wave_sum(ss);
-  const float rs = rsqrtf(ss / (float)H + eps);
   bf16* orow = out + (long)row * ldo;
-  for (int c = lane * 8; c < H; c += 512) {
-    const bf16x8 v = *(const bf16x8*)(xr + c);
-    const bf16x8 wv = *(const bf16x8*)(w + c);
-    bf16x8 o;
+  float ss = 0.f;
+  if constexpr (MAXC > 0) {
+    bf16x8 v[MAXC];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)wv[j] * round_bf16((float)v[j] * rs));
-    *(bf16x8*)(orow + c) = o;
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane * 8 + i * 512;
+      if (c < H) {
+        v[i] = *(const bf16x8*)(xr + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += (float)v[i][j] * (float)v[i][j];
+      }
+    }
+    ss = wave_sum(ss);
+    const float rs = rsqrtf(ss / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane * 8 + i * 512;
+      if (c < H) {
+        const bf16x8 wv = *(const bf16x8*)(w + c);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)wv[j] * round_bf16((float)v[i][j] * rs));
+        *(bf16x8*)(orow + c) = o;
+      }
+    }
+  } else {
+    for (int c = lane * 8; c < H; c += 512) {
+      const bf16x8 v = *(const bf16x8*)(xr + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += (float)v[j] * (float)v[j];
+    }
+    ss = wave_sum(ss);
+    const float rs = rsqrtf(ss / (float)H + eps);
+    for (int c = lane * 8; c < H; c += 512) {
+      const bf16x8 v = *(const bf16x8*)(xr + c);
+      const bf16x8 wv = *(const bf16x8*)(w + c);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)wv[j] * round_bf16((float)v[j] * rs));
+      *(bf16x8*)(orow + c) = o;
+    }
   }
 }
 
@@ -46,8 +74,15 @@ extern "C" int bagel_rmsnorm_bf16(const void* x, long ldx, void* out, long ldo, 
   BAGEL_CHECK(split_row >= rows || w_second, "bagel_rmsnorm_bf16: rows past split_row need w_second");
   BAGEL_CHECK(((uintptr_t)x | (uintptr_t)out | (uintptr_t)w_first | (uintptr_t)w_second) % 16 == 0,
               "bagel_rmsnorm_bf16: misaligned operand");
-  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
-                     (bf16*)out, ldo, rows, H, (const bf16*)w_first, (const bf16*)w_second, split_row, eps);
+  const dim3 grid((rows + 3) / 4), block(256);
+#define ARGS (const bf16*)x, ldx, (bf16*)out, ldo, rows, H, (const bf16*)w_first, (const bf16*)w_second, split_row, eps
+  if (H <= 1024)
+    hipLaunchKernelGGL(rmsnorm_kernel<2>, grid, block, 0, (hipStream_t)stream, ARGS);
+  else if (H <= 4096)
+    hipLaunchKernelGGL(rmsnorm_kernel<8>, grid, block, 0, (hipStream_t)stream, ARGS);
+  else
+    hipLaunchKernelGGL(rmsnorm_kernel<0>, grid, block, 0, (hipStream_t)stream, ARGS);
+#undef ARGS
   BAGEL_LAUNCH_CHECK();
   return 0;
 }

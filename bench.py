@@ -189,8 +189,13 @@ def main():
             flops = sum(f for _, _, f in events) / len(events)
             avg = sum(ms) / len(ms)
             ach = flops / (avg * 1e-3) / 1e12
+            # fabric-side bytes of the M = 12288 launch from the PMC passes in profiles/r01_hot_kernels_pmc.txt
+            # (2 x FETCH_SIZE + WRITE_SIZE; Infinity-Cache hits included), scaled to the average launch of this
+            # run by tile count; not collected live (counters need the profiler)
+            traffic = (4976.8e6 + 466.0e6) * flops / (2.0 * 12288 * 37888 * 3584)
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                               "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                               "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_hot_kernels_pmc.txt",
                                "kernel": "gemm256_pipelined_kernel<EPI_SWIGLU, 256, 4> (gen-expert gate+up projection)",
                                "launches_timed": len(ms), "avg_launch_ms": avg, "avg_flops_per_launch": flops}
         if not args.no_cpu_baseline and args.layers is None:
