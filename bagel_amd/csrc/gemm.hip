@@ -24,8 +24,22 @@
 #include "gemm_tile.h"
 #include "gemm_pingpong.h"
 #include "gemm_pipelined.h"
+#include <algorithm>
 
 static int g_gemm_variant = -1;  // -1: choose by problem size
+static int g_gemm_persistent = 1;  // 0: one workgroup per output tile
+
+// CUs of the current device, rounded down to a multiple of the 8 XCDs (256 on MI355X)
+static int compute_units() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 8)
+      cu = 256;
+    n = cu / 8 * 8;
+  }
+  return n;
+}
 
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(GemmParams p, int epilogue, hipStream_t stream) {
@@ -90,7 +104,7 @@ template <int BN, int WR>
 static int launch_pipelined(GemmParams p, int epilogue, hipStream_t stream) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + BN - 1) / BN;
-  const dim3 grid(p.tiles_m * p.tiles_n), block(512);
+  const dim3 grid(g_gemm_persistent ? std::min(p.tiles_m * p.tiles_n, compute_units()) : p.tiles_m * p.tiles_n), block(512);
   const size_t lds = 2 * (256 + BN) * ROW_BYTES;
   constexpr bool PAIRS = (BN / (8 / WR) / 16) % 2 == 0;  // SwiGLU needs an even number of fragments per wave
 #define LAUNCH(EPI)                                                                              \
@@ -186,3 +200,7 @@ extern "C" int bagel_gemm_bf16(const void* A, long lda, const void* W, long ldw,
 
 // Development knob: forces the tile variant bagel_gemm_bf16 launches (tools/gemm_bench.py); -1 = automatic.
 extern "C" void bagel_set_gemm_variant(int v) { g_gemm_variant = v; }
+
+// Development knob: 0 launches the pipelined tiles with one workgroup per output tile instead of one
+// persistent workgroup per CU (A/B timing in tools/step_ab.py).
+extern "C" void bagel_set_gemm_persistent(int on) { g_gemm_persistent = on; }

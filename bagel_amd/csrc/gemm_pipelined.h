@@ -11,6 +11,10 @@
 //            wait: LDS reads of tile kt done, my DMA pieces of tile kt+1 landed;  BARRIER
 //   phase 3: read frags(kt+1, ph0)    | DMA A pieces of tile kt+2 | MFMA ph3   (operands already in registers)
 //
+// Workgroups are persistent (one per CU): after an output tile's last K step the first two K tiles of the
+// workgroup's next output tile are put in flight before the epilogue, so the epilogue's stores hide their
+// latency.
+//
 // The barrier publishes tile kt+1 (every wave waited for its own DMA pieces) and retires tile kt's buffer
 // (every wave waited for its own reads of it), so that buffer can take tile kt+2's DMA right away; those
 // loads then have a whole K step (~2000 cycles) to land before they are waited for.  Phase 3's MFMAs need
@@ -33,27 +37,34 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
   constexpr bool W_EVEN = W_PIECES % NW == 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  int tile_m, tile_n;
-  gemm_tile_of_block(p, blockIdx.x, tile_m, tile_n);
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WC, wc = wave % WC;
 
+  // The workgroup is persistent: it walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x = number of
+  // CUs, a multiple of the 8 XCDs, so a workgroup's tiles stay on its XCD's share of the tile order).
+  const int ntiles = p.tiles_m * p.tiles_n;
   const int piece_row = lane >> 3;
   const int src_chunk = (lane & 7) ^ piece_row;
   const bf16* a_src[4];
   const bf16* w_src[W_ITERS];
+  int m0, n0;
+  auto set_tile = [&](int t) {
+    int tile_m, tile_n;
+    gemm_tile_of_block(p, t, tile_m, tile_n);
+    m0 = tile_m * BM;
+    n0 = tile_n * BN;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int row = (it * NW + wave) * 8 + piece_row;
-    a_src[it] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + src_chunk * 8;
-  }
+    for (int it = 0; it < 4; ++it) {
+      const int row = (it * NW + wave) * 8 + piece_row;
+      a_src[it] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + src_chunk * 8;
+    }
 #pragma unroll
-  for (int it = 0; it < W_ITERS; ++it) {
-    const int row = (it * NW + wave) * 8 + piece_row;
-    w_src[it] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + src_chunk * 8;
-  }
+    for (int it = 0; it < W_ITERS; ++it) {
+      const int row = (it * NW + wave) * 8 + piece_row;
+      w_src[it] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + src_chunk * 8;
+    }
+  };
   auto stage_a = [&](int kt) {
     char* base = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
@@ -78,10 +89,6 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
   }
 
   f32x4 acc[FN][FM];
-#pragma unroll
-  for (int i = 0; i < FN; ++i)
-#pragma unroll
-    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   bf16x8 af[2][FH], wf[2][FN];
   auto read_a = [&](const char* base, int set, int mh, int kk) {
@@ -103,26 +110,27 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
   };
 
   const int nk = p.K / BK;
-  // prologue: tiles 0 and 1 in flight, tile 0 published, phase-0 fragments of tile 0 in registers
-  stage_a(0);
-  stage_w(0);
-  if (nk > 1 && W_EVEN) {
-    stage_a(1);
-    stage_w(1);
-    // the pieces of tile 0 have landed once only tile 1's are outstanding
-    if constexpr (4 + W_ITERS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (4 + W_ITERS == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
+  auto stage_head = [&]() {  // K tiles 0 and 1 of the tile set_tile() selected
+    stage_a(0);
+    stage_w(0);
     if (nk > 1) {
       stage_a(1);
       stage_w(1);
     }
+  };
+  int t = blockIdx.x;
+  set_tile(t);
+  stage_head();
+  while (true) {
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // K tiles 0 and 1 were issued before the previous tile's epilogue (or just above): publish tile 0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  read_a(smem, 0, 0, 0);
-  read_w(smem, 0);
+    __builtin_amdgcn_s_barrier();
+    read_a(smem, 0, 0, 0);
+    read_w(smem, 0);
 
   for (int kt = 0; kt < nk; ++kt) {
     const char* base = smem + (kt & 1) * STAGE_BYTES;
@@ -152,5 +160,17 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
     mma(1, 1, 1);
   }
 
-  gemm_epilogue<EPI, FN, FM>(p, acc, m0 + wr * TM, n0 + wc * TN, lane);
+    // Both LDS stages are free once the last barrier has been passed (every wave waited for its own reads
+    // before it): start the next tile's first two K tiles now, so they land while this tile's results are
+    // being written out.
+    const int out_m = m0 + wr * TM, out_n = n0 + wc * TN;
+    const int tn = t + gridDim.x;
+    if (tn < ntiles) {
+      set_tile(tn);
+      stage_head();
+    }
+    gemm_epilogue<EPI, FN, FM>(p, acc, out_m, out_n, lane);
+    if (tn >= ntiles) break;
+    t = tn;
+  }
 }

@@ -77,4 +77,6 @@ def exchange_velocities(local_v: Optional[torch.Tensor], ex: StepExchange, width
         send[:local_v.shape[0]].copy_(local_v)
     recv = torch.empty((ex.world * ex.rows_max, width), device=device, dtype=dtype)
     dist.all_gather_into_tensor(recv, send, group=group)
-    return recv.index_select(0, ex.index.to(device))
+    if ex.index.device != recv.device:
+        ex.index = ex.index.to(recv.device)   # once per image: the plan is reused by every step
+    return recv.index_select(0, ex.index)
