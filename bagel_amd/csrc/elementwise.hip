@@ -517,13 +517,21 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const bf16* __restrict
   const bf16* row = logits + (long)blockIdx.x * ld;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const float v = (float)row[i];
+  auto take = [&](float v, int i) {
     if (v > best || (v == best && i < bi)) {
       best = v;
       bi = i;
     }
+  };
+  // 16-byte loads where the row allows it (a vocabulary row is ~300 KB), scalar loads for the ragged rest
+  const bool vec = (ld % 8 == 0) && ((uintptr_t)logits % 16 == 0);
+  const int nvec = vec ? n / 8 : 0;
+  for (int c = threadIdx.x; c < nvec; c += 256) {
+    const bf16x8 v = *(const bf16x8*)(row + 8 * c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) take((float)v[e], 8 * c + e);
   }
+  for (int i = nvec * 8 + threadIdx.x; i < n; i += 256) take((float)row[i], i);
   __shared__ float sv[256];
   __shared__ int si[256];
   sv[threadIdx.x] = best;

@@ -6,13 +6,13 @@
 // (<|vision_start|>, <|vision_end|>) per sample go through the und weights
 // (qwen2_navit.py:537-547, 604, 826-832) while thousands of latent tokens go through the gen weights.
 // The work is HBM-bound: every weight byte is read exactly once.  Each wave owns 16 output features and
-// one K slice, loads its weight rows straight into VGPRs (64 contiguous bytes per lane per 128-deep step,
-// two full cache lines per weight row), and feeds the 16x16x32 MFMA with the weights as the A operand and
-// up to four 16-row groups of X as B operands, so the weights are still read once when M > 16.
-// The k order inside an MFMA is permuted identically for both operands (a dot product does not care).
+// one K slice, loads its weight rows straight into VGPRs (two register stages, so a 4 KB step is always in
+// flight behind the one being multiplied), and feeds the 16x16x32 MFMA with the weights as the A operand
+// and up to four 16-row groups of X as B operands, so the weights are still read once when M > 16.
 // K slices leave fp32 partial sums in a workspace; a second kernel adds them in slice order and applies
 // bias / SiLU / residual / SwiGLU, so results are bitwise reproducible.
 #include "common.h"
+#include <algorithm>
 
 enum { SK_BIAS = 0, SK_RESIDUAL = 1, SK_SWIGLU = 2, SK_BIAS_SILU = 3 };
 
@@ -20,50 +20,59 @@ template <int G>
 __global__ __launch_bounds__(256) void skinny_partial_kernel(const bf16* __restrict__ X, long ldx,
                                                              const bf16* __restrict__ W, long ldw,
                                                              float* __restrict__ part, int M, int N, int K,
-                                                             int splitk) {
+                                                             int splitk, int steps_per_slice) {
   const int lane = threadIdx.x & 63;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int ngroups = N >> 4;
   if (gw >= ngroups * splitk) return;
   const int ng = gw % ngroups, s = gw / ngroups;
-  const int ks = K / splitk;
+  const int k0 = s * steps_per_slice * 128;
+  const int nsteps = min(steps_per_slice, K / 128 - s * steps_per_slice);   // the last slice may be shorter
   const int r = lane & 15, h = lane >> 4;
 
-  const bf16* wp = W + (long)(ng * 16 + r) * ldw + s * ks + h * 32;
+  // MFMA j of a 128-deep step covers k = 32 j .. 32 j + 31 of the step; lane (r, h) supplies k = 32 j + 8 h .. + 7,
+  // so one load instruction reads 64 contiguous bytes of each of the wave's 16 weight rows.
+  const bf16* wp = W + (long)(ng * 16 + r) * ldw + k0 + h * 8;
   const bf16* xp[G];
   bool xok[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     const int m = g * 16 + r;
     xok[g] = m < M;
-    xp[g] = X + (long)min(m, M - 1) * ldx + s * ks + h * 32;
+    xp[g] = X + (long)min(m, M - 1) * ldx + k0 + h * 8;
   }
   f32x4 acc[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 2
-  for (int k = 0; k < ks; k += 128) {
-    bf16x8 wf[4];
+  // two register stages: the loads of step i + 1 are in flight while step i is multiplied
+  bf16x8 wf[2][4], xf[2][G][4];
+  auto load = [&](int st, int step) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wf[j] = __builtin_nontemporal_load((const bf16x8*)(wp + k) + j);
+    for (int j = 0; j < 4; ++j) wf[st][j] = __builtin_nontemporal_load((const bf16x8*)(wp + step * 128 + j * 32));
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      bf16x8 xf[4];
+    for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        xf[j] = *((const bf16x8*)(xp[g] + k) + j);
-        if (!xok[g]) xf[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      }
+      for (int j = 0; j < 4; ++j) xf[st][g][j] = *(const bf16x8*)(xp[g] + step * 128 + j * 32);
+  };
+  auto compute = [&](int st) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[j], acc[g], 0, 0, 0);
-    }
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[st][j], xf[st][g][j], acc[g], 0, 0, 0);
+  };
+  load(0, 0);
+  for (int step = 0; step < nsteps; step += 2) {
+    if (step + 1 < nsteps) load(1, step + 1);
+    compute(0);
+    if (step + 2 < nsteps) load(0, step + 2);
+    if (step + 1 < nsteps) compute(1);
   }
-  // lane holds features n..n+3 (n = ng*16 + h*4) of row m = g*16 + r
+  // lane holds features n..n+3 (n = ng*16 + h*4) of row m = g*16 + r; rows past M carried clamped copies
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     const int m = g * 16 + r;
-    if (m < M) *(f32x4*)(part + ((long)s * M + m) * N + ng * 16 + h * 4) = acc[g];
+    if (xok[g]) *(f32x4*)(part + ((long)s * M + m) * N + ng * 16 + h * 4) = acc[g];
   }
 }
 
@@ -109,11 +118,13 @@ extern "C" int bagel_skinny_gemm_bf16(const void* X, long ldx, const void* W, lo
   BAGEL_CHECK(epilogue >= 0 && epilogue <= 3, "bagel_skinny_gemm_bf16: unknown epilogue %d", epilogue);
   if (epilogue == SK_RESIDUAL) BAGEL_CHECK(residual, "bagel_skinny_gemm_bf16: residual epilogue needs R");
   if (epilogue == SK_SWIGLU) BAGEL_CHECK(N % 32 == 0, "bagel_skinny_gemm_bf16: swiglu needs N %% 32 == 0");
-  // K slices: a divisor of K/128, at most 16, keeping the grid near 4096 waves
+  // K slices (at most 16, at least two 128-deep steps each) so that the grid has about 24 waves per CU: the
+  // kernel is latency-bound per wave, and HBM only saturates with tens of KB in flight per CU
   const int ksteps = K / 128, ngroups = N / 16;
-  int splitk = 1;
-  for (int d = 1; d <= 16; ++d)
-    if (ksteps % d == 0 && (long)ngroups * d <= 4096) splitk = d;
+  int splitk = (int)std::min<long>(16, std::max<long>(1, (6144 + ngroups - 1) / ngroups));
+  splitk = std::min(splitk, std::max(1, ksteps / 2));
+  const int steps_per_slice = (ksteps + splitk - 1) / splitk;
+  splitk = (ksteps + steps_per_slice - 1) / steps_per_slice;
   BAGEL_CHECK((long)splitk * M * N * (long)sizeof(float) <= workspace_bytes,
               "bagel_skinny_gemm_bf16: workspace too small (%ld bytes given)", workspace_bytes);
   hipStream_t st = (hipStream_t)stream;
@@ -122,10 +133,10 @@ extern "C" int bagel_skinny_gemm_bf16(const void* X, long ldx, const void* W, lo
   float* part = (float*)workspace;
   const int G = (M + 15) / 16;
   switch (G) {
-    case 1: hipLaunchKernelGGL(skinny_partial_kernel<1>, grid, block, 0, st, (const bf16*)X, ldx, (const bf16*)W, ldw, part, M, N, K, splitk); break;
-    case 2: hipLaunchKernelGGL(skinny_partial_kernel<2>, grid, block, 0, st, (const bf16*)X, ldx, (const bf16*)W, ldw, part, M, N, K, splitk); break;
-    case 3: hipLaunchKernelGGL(skinny_partial_kernel<3>, grid, block, 0, st, (const bf16*)X, ldx, (const bf16*)W, ldw, part, M, N, K, splitk); break;
-    default: hipLaunchKernelGGL(skinny_partial_kernel<4>, grid, block, 0, st, (const bf16*)X, ldx, (const bf16*)W, ldw, part, M, N, K, splitk); break;
+    case 1: hipLaunchKernelGGL(skinny_partial_kernel<1>, grid, block, 0, st, (const bf16*)X, ldx, (const bf16*)W, ldw, part, M, N, K, splitk, steps_per_slice); break;
+    case 2: hipLaunchKernelGGL(skinny_partial_kernel<2>, grid, block, 0, st, (const bf16*)X, ldx, (const bf16*)W, ldw, part, M, N, K, splitk, steps_per_slice); break;
+    case 3: hipLaunchKernelGGL(skinny_partial_kernel<3>, grid, block, 0, st, (const bf16*)X, ldx, (const bf16*)W, ldw, part, M, N, K, splitk, steps_per_slice); break;
+    default: hipLaunchKernelGGL(skinny_partial_kernel<4>, grid, block, 0, st, (const bf16*)X, ldx, (const bf16*)W, ldw, part, M, N, K, splitk, steps_per_slice); break;
   }
   BAGEL_LAUNCH_CHECK();
   const int ncols = epilogue == SK_SWIGLU ? N / 2 : N;

@@ -140,3 +140,21 @@ def test_inferencer_gen_text_and_think():
     out = inf.interleave_inference([" ".join(map(str, tc.prompts()[0]))], understanding_output=True, do_sample=False,
                                    max_think_token_n=tc.max_length)
     assert out == [text]
+
+
+def test_argmax_rows_kernel():
+    """First maximum per row, like torch.argmax: ties, ragged widths, a vocabulary-sized row, a strided view."""
+    from bagel_amd import _lib as k
+    g_ = torch.Generator().manual_seed(0)
+    for rows, n in ((3, 512), (2, 1001), (1, 152064), (5, 7)):
+        x = torch.randn((rows, n), generator=g_).to(torch.bfloat16)     # bf16 rounding makes ties common
+        x[0, n // 2] = x[0].max()                                        # an exact tie with an earlier or later maximum
+        xd = x.to("cuda:0")
+        out = torch.empty(rows, dtype=torch.int32, device="cuda:0")
+        k.argmax_rows(xd, out)
+        assert out.cpu().tolist() == torch.argmax(x.float(), dim=-1).tolist(), (rows, n)
+    wide = torch.randn((4, 1024), generator=g_).to(torch.bfloat16).to("cuda:0")
+    view = wide[:, 3:900]                                                # unaligned start, row stride 1024
+    out = torch.empty(4, dtype=torch.int32, device="cuda:0")
+    k.argmax_rows(view, out)
+    assert out.cpu().tolist() == torch.argmax(view.float().cpu(), dim=-1).tolist()
