@@ -410,6 +410,114 @@ class MoTEngine:
             values.append(torch.cat([vtws[l, :, :, ks:ks + c + n].permute(2, 0, 1) for ks, n, c in zip(kv_start, lens, ctx_lens)]).contiguous())
         return keys, values
 
+    # ---- general packed forward (the language model's forward_inference) ------------------------
+    def forward_sequence(self, seq: torch.Tensor, lens: Sequence[int], positions: Sequence[int], ctx_lens: Sequence[int],
+                         ctx_k, ctx_v, is_causal: bool, gen_rows: Optional[Sequence[int]] = None,
+                         need_kv: bool = True):
+        """Qwen2Model.forward_inference (qwen2_navit.py:1041-1115) for an already embedded packed sequence.
+
+        ``seq`` [M, H]: sample b owns ``lens[b]`` consecutive rows that attend its ``ctx_lens[b]`` context tokens
+        plus (causally or not) the sample's own rows; ``positions`` is the RoPE position of every row.
+        ``gen_rows`` (mode="gen"): rows that go through the generation expert; the others use the understanding
+        expert.  ``None`` = mode="und".  Returns (final-normed hidden states [M, H] in the given row order,
+        merged keys, merged values) with keys/values as NaiveCache holds them ([sum(ctx + len), Hkv, D] per
+        layer) or None when ``need_kv`` is false.
+
+        Rows are processed sorted by expert (generation rows first) so each expert sees one contiguous row
+        block; key slots keep the sequence order.  A causal mask needs the sequence order inside a tile, so it
+        is only offered when all rows use one expert."""
+        d, w = self.dims, self.w
+        H, I, Hq, Hkv, D, L = d.hidden_size, d.intermediate_size, d.num_heads, d.num_kv_heads, d.head_dim, d.num_layers
+        M = int(sum(lens))
+        assert seq.shape[0] == M and len(positions) == M
+        dev = self.device
+        gen = sorted(int(r) for r in gen_rows) if gen_rows is not None else []
+        gen_set = set(gen)
+        und = [r for r in range(M) if r not in gen_set]
+        Mv = len(gen)
+        if is_causal and Mv not in (0, M):
+            raise NotImplementedError("a causal mask over rows of both experts is not supported")
+        perm = gen + und                      # sorted row -> original row
+        inv = [0] * M
+        for i, r in enumerate(perm):
+            inv[r] = i
+        kv_start, row0 = [], []
+        s = r = 0
+        for n, c in zip(lens, ctx_lens):
+            kv_start.append(s)
+            row0.append(r)
+            s += (c + n + 63) // 64 * 64
+            r += n
+        S = s
+        kws = self._get("kws_seq", (L, Hkv, S, D), zero=True)
+        vtws = self._get("vtws_seq", (L, Hkv, D, S), zero=True)
+        kws.zero_()
+        vtws.zero_()
+        slot_of = [0] * M
+        tiles = []
+        for b, (n, c) in enumerate(zip(lens, ctx_lens)):
+            ks = kv_start[b]
+            if c > 0:
+                for l in range(L):
+                    kws[l, :, ks:ks + c, :].copy_(ctx_k[b][l].permute(1, 0, 2))
+                    vtws[l, :, :, ks:ks + c].copy_(ctx_v[b][l].permute(1, 2, 0))
+            rows = list(range(row0[b], row0[b] + n))
+            for j, rr in enumerate(rows):
+                slot_of[rr] = ks + c + j
+            # the sample's rows of each expert are contiguous after the sort
+            for block in ([inv[rr] for rr in rows if rr in gen_set], [inv[rr] for rr in rows if rr not in gen_set]):
+                for q0 in range(0, len(block), 128):
+                    first = block[q0]
+                    causal_base = (c + (perm[first] - row0[b])) if is_causal else -1
+                    tiles.append((first, min(128, len(block) - q0), ks, c + n, causal_base, 0, 0, 0))
+        cos, sin = rope_table([positions[r_] for r_ in perm], D, d.rope_theta, dev)
+        row_cs = torch.arange(M, dtype=torch.int32, device=dev)
+        row_slot = torch.tensor([slot_of[r_] for r_ in perm], dtype=torch.int32, device=dev)
+        tiles_t = torch.tensor(tiles, dtype=torch.int32, device=dev)
+        perm_t = torch.tensor(perm, dtype=torch.int32, device=dev)
+        qkv_dim = d.q_dim + 2 * d.kv_dim
+        X = self._get("sX", (M, H))
+        K.gather_rows(seq.to(device=dev, dtype=BF16).contiguous(), perm_t, X, M)
+        Xn = self._get("sXn", (M, H))
+        QKV = self._get("sQKV", (M, qkv_dim))
+        Q = self._get("sQ", (M, d.q_dim))
+        O = self._get("sO", (M, d.q_dim))
+        Hm = self._get("sHm", (M, I))
+        eps = d.rms_norm_eps
+        Mt = M - Mv
+
+        def linear(x, out, wts, bias=None, residual=None, kind="bias"):
+            """One projection for both row blocks: generation expert on rows [0, Mv), understanding on the rest."""
+            ep = {"bias": K.EPI_BIAS, "residual": K.EPI_RESIDUAL, "swiglu": K.EPI_SWIGLU}[kind]
+            if Mv:
+                K.gemm(x, wts[0], out, bias=None if bias is None else bias[0], residual=residual, epilogue=ep, M=Mv)
+            if Mt:
+                self._linear_und(x[Mv:], wts[1], out[Mv:], bias=None if bias is None else bias[1],
+                                 residual=None if residual is None else residual[Mv:], kind=kind)
+
+        for l, lw in enumerate(w.layers):
+            K.rmsnorm(X, Xn, lw.ln_in[0], lw.ln_in[1], Mv, eps)
+            linear(Xn, QKV, lw.wqkv, bias=lw.bqkv)
+            # mode="und" rounds the normalised q/k and the RoPE products to bf16 (qwen2_navit.py:526-530), the
+            # mixed graph keeps them in fp32 until the final cast (:549-568)
+            K.qk_norm_rope_kv(QKV, M, Hq, Hkv, D, lw.qn[0], lw.qn[1], lw.kn[0], lw.kn[1], Mv, cos, sin, row_cs, row_slot, Q,
+                              kws[l], vtws[l], S, eps, und_rounding=gen_rows is None)
+            K.varlen_attention(Q, kws[l], vtws[l], O, tiles_t, len(tiles), Hq, Hkv, D, S)
+            linear(O, X, lw.wo, residual=X, kind="residual")
+            K.rmsnorm(X, Xn, lw.ln_post[0], lw.ln_post[1], Mv, eps)
+            linear(Xn, Hm, lw.wgu, kind="swiglu")
+            linear(Hm, X, lw.wd, residual=X, kind="residual")
+        K.rmsnorm(X, Xn, w.norm[0], w.norm[1], Mv, eps)
+        hidden = torch.empty((M, H), device=dev, dtype=BF16)
+        K.gather_rows(Xn, torch.tensor(inv, dtype=torch.int32, device=dev), hidden, M)
+        keys = values = None
+        if need_kv:
+            keys = [torch.cat([kws[l, :, ks:ks + c + n, :].permute(1, 0, 2) for ks, n, c in zip(kv_start, lens, ctx_lens)]).contiguous()
+                    for l in range(L)]
+            values = [torch.cat([vtws[l, :, :, ks:ks + c + n].permute(2, 0, 1) for ks, n, c in zip(kv_start, lens, ctx_lens)]).contiguous()
+                      for l in range(L)]
+        return hidden, keys, values
+
     # ---- autoregressive text decoding ---------------------------------------------------------
     def decode_greedy(self, start_tokens: Sequence[int], pos0: Sequence[int], ctx_lens: Sequence[int],
                       ctx_k, ctx_v, max_length: int, end_token_id: Optional[int] = None, sample_fn=None,

@@ -72,6 +72,8 @@ class Bagel:
                 raise ValueError("Bagel needs a state dict (reference parameter names) or prepared MoTWeights")
             weights = MoTWeights.from_state_dict(dims, state_dict, self.device)
         self.engine = MoTEngine(dims, weights, self.device)
+        from .qwen2_navit import Qwen2ForCausalLM
+        self.language_model = Qwen2ForCausalLM(self.engine, NaiveCache)
         self.vit_tower = None
         if dims.vit is not None and state_dict is not None and "connector.fc1.weight" in state_dict:
             from .siglip import SiglipTower
