@@ -128,6 +128,17 @@ def skinny_gemm(X, W, C, workspace, bias=None, residual=None, epilogue=SK_BIAS):
     return C
 
 
+def skinny_gemm_residual_rmsnorm(X, W, C, residual, norm_weight, Xn, eps, workspace):
+    M, K = X.shape
+    N = W.shape[0]
+    assert X.dtype == W.dtype == C.dtype == Xn.dtype == torch.bfloat16 and W.shape[1] == K
+    _check(lib().bagel_skinny_gemm_residual_rmsnorm_bf16(
+        _p(X), L(X.stride(0)), _p(W), L(W.stride(0)), _p(C), L(C.stride(0)), I(M), I(N), I(K), _p(residual),
+        L(residual.stride(0)), _p(norm_weight), _p(Xn), L(Xn.stride(0)), F(eps), _p(workspace),
+        L(workspace.numel() * workspace.element_size()), _stream()), "bagel_skinny_gemm_residual_rmsnorm_bf16")
+    return C
+
+
 def rmsnorm(x, out, w_first, w_second, split_row, eps, rows=None):
     rows = x.shape[0] if rows is None else rows
     _check(lib().bagel_rmsnorm_bf16(_p(x), L(x.stride(0)), _p(out), L(out.stride(0)), I(rows), I(x.shape[1]),

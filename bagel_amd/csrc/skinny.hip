@@ -104,11 +104,56 @@ __global__ void skinny_reduce_kernel(const float* __restrict__ part, int splitk,
   C[(long)m * ldc + c] = (bf16)out;
 }
 
+// Reduce + residual + RMSNorm in one launch for the decode loop, where rows are few and every launch is
+// latency: C = bf16(bf16(sum of partials) + R) as SK_RESIDUAL does, then Xn = w * bf16(C * rsqrt(mean(C^2) + eps))
+// (Qwen2RMSNorm on the stored bf16 row, modeling_qwen2.py:54-59).  One workgroup per row.
+constexpr int RN_THREADS = 1024, RN_MAXC = 8;  // columns per thread: N <= 8192
+__global__ __launch_bounds__(RN_THREADS) void skinny_reduce_rmsnorm_kernel(const float* __restrict__ part, int splitk,
+                                                                           int M, int N, const bf16* __restrict__ R,
+                                                                           long ldr, bf16* __restrict__ C, long ldc,
+                                                                           const bf16* __restrict__ w,
+                                                                           bf16* __restrict__ Xn, long ldn, float eps) {
+  const int m = blockIdx.x;
+  float v[RN_MAXC];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < RN_MAXC; ++i) {
+    const int c = threadIdx.x + RN_THREADS * i;
+    if (c < N) {
+      // all slices' loads are issued before the first add (the row is summed by one workgroup: latency-bound);
+      // the sum runs in slice order like skinny_reduce_kernel's
+      float p[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) p[s] = s < splitk ? part[((long)s * M + m) * N + c] : 0.f;
+      float a = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) a += p[s];
+      const float o = round_bf16(round_bf16(a) + (float)R[(long)m * ldr + c]);
+      C[(long)m * ldc + c] = (bf16)o;
+      v[i] = o;
+      ss += o * o;
+    }
+  }
+  __shared__ float red[RN_THREADS / 64];
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < RN_THREADS / 64; ++i) tot += red[i];
+  const float rs = rsqrtf(tot / (float)N + eps);
+#pragma unroll
+  for (int i = 0; i < RN_MAXC; ++i) {
+    const int c = threadIdx.x + RN_THREADS * i;
+    if (c < N) Xn[(long)m * ldn + c] = (bf16)((float)w[c] * round_bf16(v[i] * rs));
+  }
+}
+
 extern "C" long bagel_skinny_gemm_workspace_bytes(int M, int N) { return (long)16 * M * N * sizeof(float); }
 
-extern "C" int bagel_skinny_gemm_bf16(const void* X, long ldx, const void* W, long ldw, void* C, long ldc, int M,
-                                      int N, int K, const void* bias, const void* residual, long ldr,
-                                      int epilogue, void* workspace, long workspace_bytes, void* stream) {
+static int skinny_launch(const void* X, long ldx, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
+                         const void* bias, const void* residual, long ldr, int epilogue, void* workspace,
+                         long workspace_bytes, const void* norm_weight, void* Xn, long ldn, float eps, void* stream) {
   BAGEL_CHECK(X && W && C && workspace, "bagel_skinny_gemm_bf16: null operand");
   BAGEL_CHECK(M > 0 && M <= 64, "bagel_skinny_gemm_bf16: M=%d outside 1..64", M);
   BAGEL_CHECK(N > 0 && N % 16 == 0, "bagel_skinny_gemm_bf16: N=%d must be a multiple of 16", N);
@@ -118,6 +163,7 @@ extern "C" int bagel_skinny_gemm_bf16(const void* X, long ldx, const void* W, lo
   BAGEL_CHECK(epilogue >= 0 && epilogue <= 3, "bagel_skinny_gemm_bf16: unknown epilogue %d", epilogue);
   if (epilogue == SK_RESIDUAL) BAGEL_CHECK(residual, "bagel_skinny_gemm_bf16: residual epilogue needs R");
   if (epilogue == SK_SWIGLU) BAGEL_CHECK(N % 32 == 0, "bagel_skinny_gemm_bf16: swiglu needs N %% 32 == 0");
+  if (norm_weight) BAGEL_CHECK(Xn && epilogue == SK_RESIDUAL && N <= RN_THREADS * RN_MAXC, "bagel_skinny_gemm_residual_rmsnorm_bf16: bad arguments");
   // K slices (at most 16, at least two 128-deep steps each) so that the grid has about 24 waves per CU: the
   // kernel is latency-bound per wave, and HBM only saturates with tens of KB in flight per CU
   const int ksteps = K / 128, ngroups = N / 16;
@@ -139,10 +185,31 @@ extern "C" int bagel_skinny_gemm_bf16(const void* X, long ldx, const void* W, lo
     default: hipLaunchKernelGGL(skinny_partial_kernel<4>, grid, block, 0, st, (const bf16*)X, ldx, (const bf16*)W, ldw, part, M, N, K, splitk, steps_per_slice); break;
   }
   BAGEL_LAUNCH_CHECK();
-  const int ncols = epilogue == SK_SWIGLU ? N / 2 : N;
-  const long total = (long)M * ncols;
-  hipLaunchKernelGGL(skinny_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part, splitk, M, N,
-                     (const bf16*)bias, (const bf16*)residual, ldr, (bf16*)C, ldc, epilogue);
+  if (norm_weight) {
+    hipLaunchKernelGGL(skinny_reduce_rmsnorm_kernel, dim3(M), dim3(RN_THREADS), 0, st, part, splitk, M, N, (const bf16*)residual,
+                       ldr, (bf16*)C, ldc, (const bf16*)norm_weight, (bf16*)Xn, ldn, eps);
+  } else {
+    const int ncols = epilogue == SK_SWIGLU ? N / 2 : N;
+    const long total = (long)M * ncols;
+    hipLaunchKernelGGL(skinny_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part, splitk, M, N,
+                       (const bf16*)bias, (const bf16*)residual, ldr, (bf16*)C, ldc, epilogue);
+  }
   BAGEL_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int bagel_skinny_gemm_bf16(const void* X, long ldx, const void* W, long ldw, void* C, long ldc, int M,
+                                      int N, int K, const void* bias, const void* residual, long ldr,
+                                      int epilogue, void* workspace, long workspace_bytes, void* stream) {
+  return skinny_launch(X, ldx, W, ldw, C, ldc, M, N, K, bias, residual, ldr, epilogue, workspace, workspace_bytes, nullptr,
+                       nullptr, 0, 0.f, stream);
+}
+
+extern "C" int bagel_skinny_gemm_residual_rmsnorm_bf16(const void* X, long ldx, const void* W, long ldw, void* C, long ldc,
+                                                       int M, int N, int K, const void* residual, long ldr,
+                                                       const void* norm_weight, void* Xn, long ldn, float eps,
+                                                       void* workspace, long workspace_bytes, void* stream) {
+  BAGEL_CHECK(norm_weight && Xn && ldn >= N, "bagel_skinny_gemm_residual_rmsnorm_bf16: null norm operand");
+  return skinny_launch(X, ldx, W, ldw, C, ldc, M, N, K, nullptr, residual, ldr, SK_RESIDUAL, workspace, workspace_bytes,
+                       norm_weight, Xn, ldn, eps, stream);
 }

@@ -579,19 +579,20 @@ class MoTEngine:
             return K.skinny_gemm(x, wt, out, skw, **kw)
 
         steps_done = 0
+        n_layers = len(w.layers)
         for t in range(max_length):
             K.gather_rows(w.embed_tokens, seq[t], X, B)
+            K.rmsnorm(X, Xn, w.layers[0].ln_in[1], None, B, eps)
             for l, lw in enumerate(w.layers):
-                K.rmsnorm(X, Xn, lw.ln_in[1], None, B, eps)
                 lin(Xn, lw.wqkv[1], QKV, bias=lw.bqkv[1])
                 K.qk_norm_rope_kv(QKV, B, Hq, Hkv, D, lw.qn[1], None, lw.kn[1], None, B, cos, sin, row_cs[t], row_slot[t],
                                   Q, kws[l], vtws[l], S, eps, und_rounding=True)
                 K.varlen_attention(Q, kws[l], vtws[l], O, tiles[t], B, Hq, Hkv, D, S)
-                lin(O, lw.wo[1], X, residual=X, epilogue=K.SK_RESIDUAL)
-                K.rmsnorm(X, Xn, lw.ln_post[1], None, B, eps)
+                # projection + residual + the RMSNorm that follows, one launch after the partial sums
+                K.skinny_gemm_residual_rmsnorm(O, lw.wo[1], X, X, lw.ln_post[1], Xn, eps, skw)
                 lin(Xn, lw.wgu[1], Hm, epilogue=K.SK_SWIGLU)
-                lin(Hm, lw.wd[1], X, residual=X, epilogue=K.SK_RESIDUAL)
-            K.rmsnorm(X, Xn, w.norm[1], None, B, eps)
+                next_norm = w.layers[l + 1].ln_in[1] if l + 1 < n_layers else w.norm[1]
+                K.skinny_gemm_residual_rmsnorm(Hm, lw.wd[1], X, X, next_norm, Xn, eps, skw)
             lin(Xn, w.lm_head, logits)
             if logits_trace is not None:
                 logits_trace.append(logits.clone())

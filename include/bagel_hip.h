@@ -50,6 +50,16 @@ int bagel_skinny_gemm_bf16(const void* X, long ldx, const void* W, long ldw, voi
                            const void* bias, const void* residual, long ldr, int epilogue, void* workspace,
                            long workspace_bytes, void* stream);
 
+/* The same product with the SK_RESIDUAL epilogue, followed in the same launch by Qwen2RMSNorm of the result row:
+ *   C = bf16(bf16(X . W^T) + residual),  Xn = norm_weight * bf16(C * rsqrt(mean(C^2) + eps))
+ * (o_proj / down_proj + residual add + the next RMSNorm of Qwen2MoTDecoderLayer.forward_inference,
+ * qwen2_navit.py:818-829, 836, and modeling_qwen2.py:54-59) for the one-token-per-sample decode loop of
+ * Bagel.generate_text (bagel.py:1551-1587).  N <= 8192. */
+int bagel_skinny_gemm_residual_rmsnorm_bf16(const void* X, long ldx, const void* W, long ldw, void* C, long ldc, int M,
+                                            int N, int K, const void* residual, long ldr, const void* norm_weight,
+                                            void* Xn, long ldn, float eps, void* workspace, long workspace_bytes,
+                                            void* stream);
+
 /* out[r] = w * bf16(x[r] * rsqrt(mean(x[r]^2) + eps)); rows < split_row use w_first, the rest w_second.
  * Replaces Qwen2RMSNorm (modeling_qwen2.py:54-59) as used per modality at qwen2_navit.py:798-800,
  * 826-829 and 1102-1104. */

@@ -158,3 +158,24 @@ def test_argmax_rows_kernel():
     out = torch.empty(4, dtype=torch.int32, device="cuda:0")
     k.argmax_rows(view, out)
     assert out.cpu().tolist() == torch.argmax(view.float().cpu(), dim=-1).tolist()
+
+
+def test_skinny_gemm_residual_rmsnorm_matches_two_step():
+    """The fused projection + residual + RMSNorm launch equals skinny GEMM (residual epilogue) followed by the
+    RMSNorm kernel, bit for bit (same partial sums, same rounding points)."""
+    from bagel_amd import _lib as k
+    g_ = torch.Generator().manual_seed(2)
+    for M, N, Kd in ((1, 3584, 3584), (5, 256, 512), (3, 3584, 18944)):
+        X = torch.randn((M, Kd), generator=g_).to(torch.bfloat16).to("cuda:0")
+        W = (torch.randn((N, Kd), generator=g_) * Kd ** -0.5).to(torch.bfloat16).to("cuda:0")
+        R = torch.randn((M, N), generator=g_).to(torch.bfloat16).to("cuda:0")
+        wn = (torch.randn(N, generator=g_) * 0.1 + 1).to(torch.bfloat16).to("cuda:0")
+        ws = torch.empty((16 * M * N,), dtype=torch.float32, device="cuda:0")
+        C1, Xn1 = R.clone(), torch.empty_like(R)
+        k.skinny_gemm(X, W, C1, ws, residual=C1, epilogue=k.SK_RESIDUAL)
+        k.rmsnorm(C1, Xn1, wn, None, M, 1e-6)
+        C2, Xn2 = R.clone(), torch.empty_like(R)
+        k.skinny_gemm_residual_rmsnorm(X, W, C2, C2, wn, Xn2, 1e-6, ws)
+        assert torch.equal(C1, C2), (M, N, Kd)
+        d = (Xn1.float() - Xn2.float()).abs().max()
+        assert float(d) <= 2.0 ** -7 * float(Xn1.float().abs().max()), (M, N, Kd, float(d))   # sum order of the row norm differs
