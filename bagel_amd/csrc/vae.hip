@@ -94,17 +94,28 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16* __restrict_
   }
 }
 
-__global__ void gn_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long npix, float eps,
-                                   float* __restrict__ stats) {
-  const int g = threadIdx.x;  // 32 groups
-  if (g >= 32) return;
+// 32 groups x 32 lanes: lane l of group g sums the partial blocks l, l + 32, ... in fp64, the group's lanes are
+// then combined through LDS in a fixed order.
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long npix,
+                                                           float eps, float* __restrict__ stats) {
+  const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
   const int cpg = C / 32;
   double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblocks; ++b)
+  for (int b = l; b < nblocks; b += 32)
     for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
       s += part[((long)b * C + c) * 2];
       q += part[((long)b * C + c) * 2 + 1];
     }
+  __shared__ double sh_s[32][33], sh_q[32][33];
+  sh_s[g][l] = s;
+  sh_q[g][l] = q;
+  __syncthreads();
+  if (l != 0) return;
+  s = q = 0.0;
+  for (int i = 0; i < 32; ++i) {
+    s += sh_s[g][i];
+    q += sh_q[g][i];
+  }
   const double n = (double)npix * cpg;
   const double mean = s / n;
   const double var = q / n - mean * mean;
@@ -147,7 +158,7 @@ extern "C" int bagel_groupnorm_swish_nhwc_bf16(const void* x, long npix, int C, 
   const int ppb = 256 / (C / 8);
   const int nblocks = (int)((npix + ppb - 1) / ppb < GN_BLOCKS ? (npix + ppb - 1) / ppb : GN_BLOCKS);
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nblocks), dim3(256), 0, st, (const bf16*)x, npix, C, part);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(64), 0, st, part, nblocks, C, npix, eps, stats);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nblocks, C, npix, eps, stats);
   const long n = npix * (C / 8);
   hipLaunchKernelGGL(gn_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const bf16*)x, npix, C, stats,
                      (const float*)gamma_f32, (const float*)beta_f32, swish, (bf16*)out);
