@@ -519,7 +519,7 @@ class MoTEngine:
         return hidden, keys, values
 
     # ---- autoregressive text decoding ---------------------------------------------------------
-    def decode_greedy(self, start_tokens: Sequence[int], pos0: Sequence[int], ctx_lens: Sequence[int],
+    def decode_tokens(self, start_tokens: Sequence[int], pos0: Sequence[int], ctx_lens: Sequence[int],
                       ctx_k, ctx_v, max_length: int, end_token_id: Optional[int] = None, sample_fn=None,
                       logits_trace: Optional[list] = None) -> torch.Tensor:
         """Bagel.generate_text (bagel.py:1526-1596): one token per sample per step through the understanding
@@ -571,7 +571,7 @@ class MoTEngine:
         Hm = self._get("dHm", (B, I))
         V = w.lm_head.shape[0]
         logits = self._get("dlogits", (B, V))
-        assert 1 <= B <= 64, "decode_greedy handles 1..64 samples per call"
+        assert 1 <= B <= 64, "decode_tokens handles 1..64 samples per call"
         skw = self._get("skinny_ws_dec", (16 * B * max(2 * I, qkv_dim, V),), dtype=torch.float32)
         eps = d.rms_norm_eps
 

@@ -392,7 +392,7 @@ class Bagel:
             def sample_fn(logits):
                 probs = torch.softmax(logits.float() / temperature, dim=-1)
                 return torch.multinomial(probs, num_samples=1).squeeze(1)
-        return self.engine.decode_greedy(cpu(packed_start_tokens).tolist(), cpu(packed_query_position_ids).tolist(), kvl,
+        return self.engine.decode_tokens(cpu(packed_start_tokens).tolist(), cpu(packed_query_position_ids).tolist(), kvl,
                                          ctx_k, ctx_v, max_length, end_token_id=end_token_id, sample_fn=sample_fn,
                                          logits_trace=logits_trace)
 

@@ -10,7 +10,10 @@ the whole batch (N images on N GPUs: weak scaling, three units per rank per CFG 
 VAE decode of every image to uint8.
 Inputs (weights, context KV, noise) are resident in HBM before the timed region.
 
-Prints ONE JSON line; see DESIGN.md for the meaning of ``roofline`` and ``cpu_baseline``.
+Prints ONE JSON line.  ``roofline`` describes the dominant kernel (the generation expert's gate+up GEMM): achieved
+TFLOP/s from HIP events around its launches inside the timed region against the dense bf16 MFMA peak, plus
+fabric-side bytes per launch from separate counter passes.  ``cpu_baseline`` is the CPU checker timed on this
+host's cores on a bounded sample (a reported baseline, not a target).
 """
 from __future__ import annotations
 

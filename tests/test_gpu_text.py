@@ -54,7 +54,7 @@ def test_generate_text_teacher_forced_logits(name):
         return ref_tokens[min(step[0], ref_tokens.shape[0] - 1)]
 
     trace = []
-    model.engine.decode_greedy(gi["packed_start_tokens"].tolist(), gi["packed_query_position_ids"].tolist(),
+    model.engine.decode_tokens(gi["packed_start_tokens"].tolist(), gi["packed_query_position_ids"].tolist(),
                                kvlens, *_split_ctx(model, past, kvlens), tc.max_length, sample_fn=forced,
                                logits_trace=trace)
     logits = torch.stack(trace).float().cpu()
