@@ -68,6 +68,6 @@ def test_image_transform_output():
     img = Image.fromarray((np.arange(64 * 48 * 3) % 256).astype(np.uint8).reshape(48, 64, 3))
     t = ImageTransform(128, 32, 16)(img)
     assert t.shape == (3, 48, 64) and t.dtype == torch.float32
-    assert torch.allclose(t, torch.from_numpy(np.asarray(img)).permute(2, 0, 1).float() / 255 * 2 - 1)
+    assert torch.allclose(t, torch.from_numpy(np.array(img)).permute(2, 0, 1).float() / 255 * 2 - 1)
     rgba = Image.new("RGBA", (4, 4), (255, 0, 0, 0))
     assert pil_img2rgb(rgba).getpixel((0, 0)) == (255, 255, 255)   # transparent -> white
