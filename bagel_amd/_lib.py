@@ -198,6 +198,18 @@ def cast_f32_bf16(x, out):
     _check(lib().bagel_cast_f32_bf16(_p(x), _p(out), L(x.numel()), _stream()), "bagel_cast_f32_bf16")
 
 
+def taylor_update(feature, factors, n_new, distance):
+    rows, H = feature.shape
+    _check(lib().bagel_taylor_update_bf16(_p(feature), L(feature.stride(0)), I(rows), I(H), _p(factors),
+                                          L(factors.stride(0)), I(n_new), I(distance), _stream()),
+           "bagel_taylor_update_bf16")
+
+
+def taylor_eval(factors, rows, H, n_factors, x, out):
+    _check(lib().bagel_taylor_eval_bf16(_p(factors), L(factors.stride(0)), I(rows), I(H), I(n_factors), I(x), _p(out),
+                                        L(out.stride(0)), _stream()), "bagel_taylor_eval_bf16")
+
+
 def argmax_rows(logits, out):
     rows, n = logits.shape
     _check(lib().bagel_argmax_rows_bf16(_p(logits), L(logits.stride(0)), I(rows), I(n), _p(out), _stream()),

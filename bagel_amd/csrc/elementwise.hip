@@ -674,3 +674,81 @@ extern "C" int bagel_split_heads_pad_bf16(const void* qkv, long ld, int M, int h
   BAGEL_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// TaylorSeer feature cache (modeling/cache_utils/taylorseer.py), elementwise over n bf16 values.
+// F holds the factors [order][factor_stride >= n].  Every tensor op of the reference rounds to bf16; so do these.
+// update (derivative_approximation, :11-29): new_0 = feature, new_{i+1} = bf16(bf16(new_i - old_i) / distance)
+//   for i < n_new - 1, where the caller decides n_new (at most n_old + 1 and at most 7).
+// eval (taylor_formula, :31-45): out = sum_i bf16(bf16(float(1 / i!) * F_i) * x^i), added in bf16.
+// ---------------------------------------------------------------------------------------------
+constexpr int TAYLOR_MAX = 7;
+
+__global__ __launch_bounds__(256) void taylor_update_kernel(const bf16* __restrict__ feature, long ldf, int H,
+                                                            bf16* __restrict__ F, long fs, long n, int n_new, float distance) {
+  const long idx = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (idx >= n) return;
+  const long row = idx / H;
+  const int col = idx - row * H;
+  bf16x8 cur = *(const bf16x8*)(feature + row * ldf + col);
+#pragma unroll
+  for (int i = 0; i < TAYLOR_MAX; ++i) {
+    if (i >= n_new) break;
+    bf16x8 nxt;
+    if (i + 1 < n_new) {
+      const bf16x8 old = *(const bf16x8*)(F + (long)i * fs + idx);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) nxt[e] = (bf16)(round_bf16((float)cur[e] - (float)old[e]) / distance);
+    }
+    *(bf16x8*)(F + (long)i * fs + idx) = cur;
+    cur = nxt;
+  }
+}
+
+__global__ __launch_bounds__(256) void taylor_eval_kernel(const bf16* __restrict__ F, long fs, long n, int n_factors, int x,
+                                                          bf16* __restrict__ out, long ldo, int H) {
+  const long idx = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (idx >= n) return;
+  const long row = idx / H;
+  const int col = idx - row * H;
+  bf16x8 acc = *(const bf16x8*)(F + idx);   // order 0: 1/0! * F_0 * x^0
+  float coef = 1.f, xp = 1.f;
+  double fact = 1.0;
+#pragma unroll
+  for (int i = 1; i < TAYLOR_MAX; ++i) {
+    if (i >= n_factors) break;
+    fact *= (double)i;
+    coef = (float)(1.0 / fact);
+    xp *= (float)x;
+    const bf16x8 f = *(const bf16x8*)(F + (long)i * fs + idx);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = (bf16)((float)acc[e] + round_bf16(round_bf16(coef * (float)f[e]) * xp));
+  }
+  *(bf16x8*)(out + row * ldo + col) = acc;
+}
+
+extern "C" int bagel_taylor_update_bf16(const void* feature, long ldf, int rows, int H, void* factors,
+                                        long factor_stride, int n_new, int distance, void* stream) {
+  BAGEL_CHECK(feature && factors && rows > 0 && H > 0 && H % 8 == 0 && ldf % 8 == 0 && ldf >= H,
+              "bagel_taylor_update_bf16: bad arguments");
+  BAGEL_CHECK(n_new >= 1 && n_new <= TAYLOR_MAX && (n_new == 1 || distance > 0), "bagel_taylor_update_bf16: bad order %d", n_new);
+  const long n = (long)rows * H;
+  BAGEL_CHECK(factor_stride >= n && factor_stride % 8 == 0, "bagel_taylor_update_bf16: bad factor stride");
+  hipLaunchKernelGGL(taylor_update_kernel, dim3((n / 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)feature, ldf, H, (bf16*)factors, factor_stride, n, n_new, (float)distance);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int bagel_taylor_eval_bf16(const void* factors, long factor_stride, int rows, int H, int n_factors, int x,
+                                      void* out, long ldo, void* stream) {
+  BAGEL_CHECK(factors && out && rows > 0 && H > 0 && H % 8 == 0 && ldo % 8 == 0 && ldo >= H,
+              "bagel_taylor_eval_bf16: bad arguments");
+  BAGEL_CHECK(n_factors >= 1 && n_factors <= TAYLOR_MAX && x >= 0, "bagel_taylor_eval_bf16: bad order %d", n_factors);
+  const long n = (long)rows * H;
+  BAGEL_CHECK(factor_stride >= n && factor_stride % 8 == 0, "bagel_taylor_eval_bf16: bad factor stride");
+  hipLaunchKernelGGL(taylor_eval_kernel, dim3((n / 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)factors, factor_stride, n, n_factors, x, (bf16*)out, ldo, H);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}

@@ -135,6 +135,57 @@ class MoTWeights:
 
 
 @dataclass
+class TaylorStep:
+    """What forward_gen does with the TaylorSeer cache in one step."""
+    kind: str                   # "full": update the cache after the layers; "Taylor": skip the layers
+    factors: torch.Tensor       # [7, rows * H] bf16, rows = latent rows of the step's plan (a prefix of the full plan's)
+    n_factors: int              # full: factors the cache holds after this update; Taylor: factors to sum
+    distance: int = 1           # full: steps since the previous full step
+    x: int = 0                  # Taylor: steps since the last full step
+
+
+class TaylorSchedule:
+    """Step types and factor counts of one CFG branch: cal_type / force_scheduler / derivative_approximation of
+    modeling/cache_utils/taylorseer.py:11-29, 61-117 with cache_init's constants (:123-153: fresh_threshold 3,
+    max_order 6, first_enhance 5, taylor_cache on)."""
+    FRESH, MAX_ORDER, FIRST = 3, 6, 5
+
+    def __init__(self):
+        self.step = 0
+        self.activated = [0]
+        self.counter = 0
+        self.n_factors = 0
+        self.kind = "full"
+
+    def advance(self):
+        """Call once per forward of the branch, before it: decides the step type (cal_type)."""
+        first = self.step < self.FIRST
+        if first or self.counter == self.FRESH - 1:
+            self.kind = "full"
+            self.counter = 0
+            self.activated.append(self.step)
+            if self.step == 0:
+                self.n_factors = 0                       # taylor_cache_init
+            # derivative_approximation: one more order per full step once step > first_enhance - 2
+            self.n_factors = min(self.n_factors + 1, self.MAX_ORDER + 1) if (self.n_factors and self.step > self.FIRST - 2) else 1
+        else:
+            self.counter += 1
+            self.kind = "Taylor"
+        return self.kind
+
+    @property
+    def distance(self):
+        return self.activated[-1] - self.activated[-2]
+
+    @property
+    def x(self):
+        return self.step - self.activated[-1]
+
+    def done(self):
+        self.step += 1
+
+
+@dataclass
 class GenUnit:
     """One (sample, CFG branch) pair of a flow step."""
     sample: int                 # index into the packed batch
@@ -259,10 +310,16 @@ class MoTEngine:
         for r0 in range(0, Mt, 64):
             fn(r0, min(64, Mt - r0))
 
-    def forward_gen(self, plan: GenPlan, x_bf16: torch.Tensor, temb: torch.Tensor, text_emb: torch.Tensor):
+    def forward_gen(self, plan: GenPlan, x_bf16: torch.Tensor, temb: torch.Tensor, text_emb: torch.Tensor,
+                    taylor: Optional["TaylorStep"] = None):
         """x_bf16 [rows of the packed latent, P], temb [H], text_emb [Mt, H] -> velocities [Mv, P] (bf16),
         rows in unit order.  Mirrors Bagel._forward_flow's embedding + forward_inference(mode="gen") +
-        llm2vae for all units at once (bagel.py:1389-1426, qwen2_navit.py:1041-1115)."""
+        llm2vae for all units at once (bagel.py:1389-1426, qwen2_navit.py:1041-1115).
+
+        ``taylor`` (TaylorSeer, qwen2_navit.py:838-843): on a "full" step the last layer's output of the latent
+        rows updates the factor cache; on a "Taylor" step the whole stack is skipped and that output is the
+        Taylor expansion of the cache (every layer of the reference returns its own expansion and ignores its
+        input, so only the last layer's reaches the head)."""
         d, w = self.dims, self.w
         H, I, Hq, Hkv, D = d.hidden_size, d.intermediate_size, d.num_heads, d.num_kv_heads, d.head_dim
         Mv, Mt, M = plan.Mv, plan.Mt, plan.M
@@ -277,6 +334,12 @@ class MoTEngine:
         Vout = self._get("Vout", (Mv, d.patch_latent_dim))
         skw = self._get("skinny_ws", (16 * 64 * max(2 * I, qkv_dim),), dtype=torch.float32)
         eps = d.rms_norm_eps
+
+        if taylor is not None and taylor.kind == "Taylor":
+            K.taylor_eval(taylor.factors, Mv, H, taylor.n_factors, taylor.x, X)
+            K.rmsnorm(X, Xn, w.norm[0], w.norm[1], Mv, eps, rows=Mv)
+            K.gemm(Xn, w.l2v_w, Vout, bias=w.l2v_b, M=Mv)
+            return Vout
 
         # embedding: vae2llm(x_t) + t_emb + pos_embed on latent rows, embed_tokens on text rows
         K.gemm(x_bf16, w.v2l_w, lin, bias=w.v2l_b)
@@ -310,6 +373,8 @@ class MoTEngine:
             self._und_rows(lambda r0, n: K.skinny_gemm(Hm[Mv + r0:Mv + r0 + n], lw.wd[1], X[Mv + r0:Mv + r0 + n], skw,
                                                        residual=X[Mv + r0:Mv + r0 + n], epilogue=K.SK_RESIDUAL), Mt)
 
+        if taylor is not None:
+            K.taylor_update(X[:Mv], taylor.factors, taylor.n_factors, taylor.distance)
         # final norm + llm2vae on the latent rows only (the text rows' outputs are never read, bagel.py:1426)
         K.rmsnorm(X, Xn, w.norm[0], w.norm[1], Mv, eps, rows=Mv)
         K.gemm(Xn, w.l2v_w, Vout, bias=w.l2v_b, M=Mv)

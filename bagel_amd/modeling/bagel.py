@@ -13,7 +13,7 @@ import torch
 
 from .. import _lib as K
 from ..config import BagelDims
-from ..engine import GenUnit, MoTEngine, MoTWeights
+from ..engine import GenUnit, MoTEngine, MoTWeights, TaylorSchedule, TaylorStep
 from ..parallel import exchange_velocities, plan_exchange, world_info
 
 BF16 = torch.bfloat16
@@ -552,12 +552,12 @@ class Bagel:
         group=None,
     ):
         """Bagel.generate_image (bagel.py:1237-1347).  Returns a tuple of per-image ``[Nv, 64]`` fp32 latents
-        (on the device).  ``enable_taylorseer`` changes results by design and is not offered here.
+        (on the device).  ``enable_taylorseer`` skips two of three forwards after the first five steps and
+        extrapolates the last layer's output instead (modeling/cache_utils/taylorseer.py); it is offered when all
+        CFG branches start at step 0, so that their schedules coincide and the packed forward stays one launch.
         When torch.distributed is initialised with more than one rank, the (sample, branch) units of each
         step are split over the ranks of ``group`` (bagel_amd/parallel.py); every rank must make the same call
         and every rank returns the same latents."""
-        if enable_taylorseer:
-            raise NotImplementedError("TaylorSeer step skipping is an approximation and is not implemented")
         if cfg_renorm_type not in K.RENORM and cfg_text_scale > 1.0:
             raise NotImplementedError(f"{cfg_renorm_type} is not suppoprted")
         eng, d, dev = self.engine, self.dims, self.device
@@ -623,6 +623,14 @@ class Bagel:
         v_t = torch.empty((Nv, d.patch_latent_dim), device=dev, dtype=BF16)
         cfg_ws = torch.empty(K.cfg_workspace_bytes(Nv, d.patch_latent_dim), device=dev, dtype=torch.uint8)
 
+        # TaylorSeer: one schedule per CFG branch as in the reference (bagel.py:1273-1277); the factor cache covers
+        # the latent rows of the full plan, whose first rows are the cond plan's
+        schedules = factors = None
+        if enable_taylorseer:
+            schedules = {b: TaylorSchedule() for b in (0, 1, 2)}
+            rows_max = max(p_.Mv for p_ in (plan_full, plan_cond) if p_ is not None) if (plan_full or plan_cond) else 0
+            factors = torch.empty((7, max(rows_max, 1) * d.hidden_size), device=dev, dtype=BF16)
+
         for i, t in enumerate(timesteps.tolist()):
             if max_steps is not None and i >= max_steps:
                 break
@@ -633,7 +641,21 @@ class Bagel:
             ts_, is_ = (cfg_text_scale, cfg_img_scale) if active else (1.0, 1.0)
             full = active and use_text
             plan, ex = (plan_full, ex_full) if full else (plan_cond, ex_cond)
-            vloc = eng.forward_gen(plan, x_bf16, temb_table[i], text_emb[id(plan)]) if plan is not None else None
+            tstep = None
+            if schedules is not None:
+                active_br = [0] + ([1] if full else []) + ([2] if (full and use_img) else [])
+                kinds = {schedules[b].advance() for b in active_br}
+                counts = {schedules[b].n_factors for b in active_br}
+                if len(kinds) != 1 or len(counts) != 1:
+                    raise NotImplementedError("TaylorSeer with CFG branches that start after step 0 (their skip schedules "
+                                              "differ from the cond branch's) is not supported")
+                sch = schedules[0]
+                if plan is not None:
+                    tstep = TaylorStep(kind=sch.kind, factors=factors[:, :plan.Mv * d.hidden_size], n_factors=sch.n_factors,
+                                       distance=sch.distance, x=sch.x)
+                for b in active_br:
+                    schedules[b].done()
+            vloc = eng.forward_gen(plan, x_bf16, temb_table[i], text_emb[id(plan)], taylor=tstep) if plan is not None else None
             vout = exchange_velocities(vloc, ex, d.patch_latent_dim, dev, BF16, group)
             v_cond = vout[:Nv]
             v_text = vout[Nv:2 * Nv] if full else None

@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--resolution", type=int, default=1024)
     ap.add_argument("--num-timesteps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--taylorseer", action="store_true",
+                    help="enable_taylorseer=True (two of three forwards skipped after step 4): a different workload, "
+                         "not the headline configuration")
     return ap.parse_args()
 
 
@@ -128,7 +131,7 @@ def main():
             cfg_img_packed_position_ids=gm["cfg_packed_position_ids"],
             cfg_img_packed_query_indexes=gm["cfg_packed_query_indexes"],
             cfg_img_key_values_lens=gm["cfg_key_values_lens"],
-            cfg_img_packed_key_value_indexes=gm["cfg_packed_key_value_indexes"], **gi)
+            cfg_img_packed_key_value_indexes=gm["cfg_packed_key_value_indexes"], enable_taylorseer=args.taylorseer, **gi)
 
     # FLUX VAE decoder (random-init at the true FLUX dims); images are decoded by the rank that owns them
     from bagel_amd.config import VAEDims
@@ -185,7 +188,7 @@ def main():
                                    f"num_timesteps={args.num_timesteps}, cfg_text 4.0 + cfg_img 1.5, "
                                    f"cfg_interval (0.4,1.0), global renorm, random-init weights, 34-token context; "
                                    f"one step = one generate_image call for the batch + VAE decode to uint8 of every image",
-                       "global_batch": B, "units_per_rank_per_cfg_step": 3, "parallelism": f"cfg-branch x batch over {world} GPU"},
+                       "taylorseer": bool(args.taylorseer), "global_batch": B, "units_per_rank_per_cfg_step": 3, "parallelism": f"cfg-branch x batch over {world} GPU"},
         }
         if events:
             ms = [a.elapsed_time(b) for a, b, _ in events]

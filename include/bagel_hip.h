@@ -121,6 +121,16 @@ int bagel_timestep_sinusoid_bf16(const void* t, int n, int dim, void* out, void*
 
 int bagel_cast_f32_bf16(const void* x, void* out, long n, void* stream);
 
+/* TaylorSeer feature cache of the last decoder layer (modeling/cache_utils/taylorseer.py:11-45 as used at
+ * qwen2_navit.py:838-843): factors [7][factor_stride] bf16 (factor_stride >= rows * H elements), every elementwise op rounded to bf16 like the
+ * reference's tensor arithmetic.
+ *   update: F_0 = feature, F_{i+1} = ((F_i_new - F_i_old) / distance) for i < n_new - 1   (a full step)
+ *   eval:   out = sum_{i < n_factors} (1 / i!) * F_i * x^i                                 (a skipped step) */
+int bagel_taylor_update_bf16(const void* feature, long ldf, int rows, int H, void* factors, long factor_stride,
+                             int n_new, int distance, void* stream);
+int bagel_taylor_eval_bf16(const void* factors, long factor_stride, int rows, int H, int n_factors, int x, void* out,
+                           long ldo, void* stream);
+
 /* out[r] = index of the first maximum of logits[r][0..n) (int32): torch.argmax at bagel.py:1580. */
 int bagel_argmax_rows_bf16(const void* logits, long ld, int rows, int n, void* out_i32, void* stream);
 

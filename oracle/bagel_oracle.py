@@ -238,16 +238,78 @@ def layer_inference(p, dims, layer_idx, x, query_lens, cos, sin, packed_query_in
     return residual + h, past
 
 
+class TaylorState:
+    """One branch's TaylorSeer bookkeeping: modeling/cache_utils/taylorseer.py:58-153 with the constants of
+    cache_init (fresh_threshold 3, max_order 6, first_enhance 5, taylor_cache on).
+
+    On a 'Taylor' step every decoder layer returns the Taylor expansion of its own cached output and ignores its
+    input (qwen2_navit.py:838-843), so only the LAST layer's factors reach the model output; they are the only
+    ones kept here."""
+
+    def __init__(self, num_steps: int):
+        self.step = 0
+        self.num_steps = num_steps
+        self.activated_steps = [0]
+        self.cache_counter = 0
+        self.fresh_threshold, self.max_order, self.first_enhance = 3, 6, 5
+        self.cal_threshold = None
+        self.factors: Dict[int, torch.Tensor] = {}
+        self.type = "full"
+
+    def cal_type(self):
+        """taylorseer.py:83-117 (the taylor_cache branch) + force_scheduler (:61-77, step weight 0)."""
+        first = self.step < self.first_enhance
+        interval = self.fresh_threshold if first else self.cal_threshold
+        if first or self.cache_counter == interval - 1:
+            self.type = "full"
+            self.cache_counter = 0
+            self.activated_steps.append(self.step)
+            self.cal_threshold = round(self.fresh_threshold / 1.0)
+        else:
+            self.cache_counter += 1
+            self.type = "Taylor"
+
+    def update(self, feature: torch.Tensor):
+        """derivative_approximation, taylorseer.py:11-29."""
+        distance = self.activated_steps[-1] - self.activated_steps[-2]
+        new = {0: feature}
+        for i in range(self.max_order):
+            if self.factors.get(i) is not None and self.step > self.first_enhance - 2:
+                new[i + 1] = (new[i] - self.factors[i]) / distance
+            else:
+                break
+        self.factors = new
+
+    def expand(self) -> torch.Tensor:
+        """taylor_formula, taylorseer.py:31-45."""
+        x = self.step - self.activated_steps[-1]
+        out = 0
+        for i in range(len(self.factors)):
+            out = out + (1 / math.factorial(i)) * self.factors[i] * (x ** i)
+        return out
+
+
 def llm_forward_inference(p, dims, x, query_lens, packed_query_position_ids, packed_query_indexes,
                           past=None, key_values_lens=None, packed_key_value_indexes=None,
                           update_past_key_values=True, is_causal=True, mode="und",
-                          packed_vae_token_indexes=None, packed_text_indexes=None):
-    """Qwen2Model.forward_inference, qwen2_navit.py:1041-1115."""
+                          packed_vae_token_indexes=None, packed_text_indexes=None, taylor: Optional[TaylorState] = None):
+    """Qwen2Model.forward_inference, qwen2_navit.py:1041-1115; ``taylor``: this branch's TaylorSeer state."""
     cos, sin = rotary_cos_sin(packed_query_position_ids, dims.head_dim, dims.rope_theta, x.dtype)
+    if taylor is not None:
+        taylor.cal_type()
+        if taylor.type == "full" and taylor.step == 0:
+            taylor.factors = {}                      # taylor_cache_init, taylorseer.py:47-56
     for i in range(dims.num_layers):
+        if taylor is not None and taylor.type == "Taylor":
+            x = taylor.expand()
+            break
         x, past = layer_inference(p, dims, i, x, query_lens, cos, sin, packed_query_indexes, past,
                                   key_values_lens, packed_key_value_indexes, update_past_key_values,
                                   is_causal, mode, packed_vae_token_indexes, packed_text_indexes)
+    if taylor is not None:
+        if taylor.type == "full":
+            taylor.update(x)
+        taylor.step += 1
     eps = dims.rms_norm_eps
     if mode == "und":
         x = rms_norm(x, p["language_model.model.norm.weight"], eps)
@@ -479,8 +541,8 @@ def forward_flow(p, dims, x_t, timestep, packed_vae_token_indexes, packed_vae_po
                  cfg_text_packed_key_value_indexes=None,
                  cfg_img_scale=1.0, cfg_img_packed_position_ids=None, cfg_img_packed_query_indexes=None,
                  cfg_img_key_values_lens=None, cfg_img_past_key_values=None,
-                 cfg_img_packed_key_value_indexes=None, return_branches=False):
-    """Bagel._forward_flow, bagel.py:1350-1500."""
+                 cfg_img_packed_key_value_indexes=None, return_branches=False, taylor=None):
+    """Bagel._forward_flow, bagel.py:1350-1500.  ``taylor``: {"cond", "text", "img"} -> TaylorState."""
     emb = p["language_model.model.embed_tokens.weight"][packed_text_ids]
     seq = emb.new_zeros((int(sum(packed_seqlens)), dims.hidden_size))
     seq[packed_text_indexes] = emb
@@ -490,21 +552,22 @@ def forward_flow(p, dims, x_t, timestep, packed_vae_token_indexes, packed_vae_po
     h = linear(x_t, p["vae2llm.weight"], p["vae2llm.bias"]) + temb + pos
     seq[packed_vae_token_indexes] = h.to(seq.dtype)
 
-    def branch(pos_ids, q_idx, past, kvl, kv_idx):
+    def branch(pos_ids, q_idx, past, kvl, kv_idx, which):
         out, _ = llm_forward_inference(p, dims, seq, packed_seqlens, pos_ids, q_idx, past, kvl, kv_idx,
                                        update_past_key_values=False, is_causal=False, mode="gen",
                                        packed_vae_token_indexes=packed_vae_token_indexes,
-                                       packed_text_indexes=packed_text_indexes)
+                                       packed_text_indexes=packed_text_indexes,
+                                       taylor=None if taylor is None else taylor[which])
         return linear(out, p["llm2vae.weight"], p["llm2vae.bias"])[packed_vae_token_indexes]
 
-    v_t = branch(packed_position_ids, packed_indexes, past_key_values, key_values_lens, packed_key_value_indexes)
+    v_t = branch(packed_position_ids, packed_indexes, past_key_values, key_values_lens, packed_key_value_indexes, "cond")
     v_text = v_img = None
     if cfg_text_scale > 1.0:
         v_text = branch(cfg_text_packed_position_ids, cfg_text_packed_query_indexes, cfg_text_past_key_values,
-                        cfg_text_key_values_lens, cfg_text_packed_key_value_indexes)
+                        cfg_text_key_values_lens, cfg_text_packed_key_value_indexes, "text")
     if cfg_img_scale > 1.0:
         v_img = branch(cfg_img_packed_position_ids, cfg_img_packed_query_indexes, cfg_img_past_key_values,
-                       cfg_img_key_values_lens, cfg_img_packed_key_value_indexes)
+                       cfg_img_key_values_lens, cfg_img_packed_key_value_indexes, "img")
     out = cfg_combine(v_t, v_text, v_img, cfg_text_scale, cfg_img_scale, cfg_renorm_min, cfg_renorm_type)
     if return_branches:
         return out, (v_t, v_text, v_img)
@@ -523,13 +586,17 @@ def generate_image(p, dims, packed_text_ids, packed_text_indexes, packed_init_no
                    past_key_values, key_values_lens, packed_key_value_indexes, num_timesteps=24,
                    timestep_shift=1.0, cfg_renorm_min=0.0, cfg_renorm_type="global", cfg_interval=(0, 1),
                    cfg_text_scale=1.0, cfg_img_scale=1.0, trace: Optional[list] = None, max_steps=None,
-                   **cfg_kwargs):
-    """Bagel.generate_image, bagel.py:1237-1347 (TaylorSeer off).  ``trace`` collects per-step tensors."""
+                   enable_taylorseer=False, teacher_x=None, **cfg_kwargs):
+    """Bagel.generate_image, bagel.py:1237-1347.  ``trace`` collects per-step tensors; ``teacher_x`` replaces the
+    state before every step (a list of per-step inputs)."""
     x_t = packed_init_noises
+    taylor = {k: TaylorState(num_timesteps) for k in ("cond", "text", "img")} if enable_taylorseer else None
     timesteps, dts = flow_timesteps(num_timesteps, timestep_shift)
     for i, t in enumerate(timesteps):
         if max_steps is not None and i >= max_steps:
             break
+        if teacher_x is not None:
+            x_t = teacher_x[i]
         timestep = torch.tensor([t] * x_t.shape[0])
         if t > cfg_interval[0] and t <= cfg_interval[1]:
             ts_, is_ = cfg_text_scale, cfg_img_scale
@@ -539,7 +606,7 @@ def generate_image(p, dims, packed_text_ids, packed_text_indexes, packed_init_no
                                packed_text_ids, packed_text_indexes, packed_indexes, packed_position_ids,
                                packed_seqlens, key_values_lens, past_key_values, packed_key_value_indexes,
                                cfg_renorm_min=cfg_renorm_min, cfg_renorm_type=cfg_renorm_type,
-                               cfg_text_scale=ts_, cfg_img_scale=is_, return_branches=True, **cfg_kwargs)
+                               cfg_text_scale=ts_, cfg_img_scale=is_, return_branches=True, taylor=taylor, **cfg_kwargs)
         if trace is not None:
             trace.append({"x_t": x_t, "v_t": v_t, "v_cond": br[0], "v_text": br[1], "v_img": br[2]})
         x_t = x_t - v_t.to(x_t.device) * dts[i]

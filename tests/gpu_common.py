@@ -47,4 +47,4 @@ def run_scenario_on_gpu(sc, run, trace=None, max_steps=None, teacher_x=None):
         cfg_img_packed_query_indexes=gm["cfg_packed_query_indexes"],
         cfg_img_key_values_lens=gm["cfg_key_values_lens"],
         cfg_img_packed_key_value_indexes=gm["cfg_packed_key_value_indexes"],
-        max_steps=max_steps, trace=trace, teacher_x=teacher_x, **gi)
+        max_steps=max_steps, trace=trace, teacher_x=teacher_x, enable_taylorseer=sc.enable_taylorseer, **gi)

@@ -153,11 +153,11 @@ class OracleRun:
             cfg_text_scale=ts_, cfg_img_scale=is_, return_branches=True, **self.cfg_kwargs())
 
     @torch.no_grad()
-    def generate(self, trace=None, max_steps=None):
+    def generate(self, trace=None, max_steps=None, teacher_x=None):
         sc, gi = self.sc, self.gi
         return O.generate_image(
             self.sd, self.dims, past_key_values=self.ctx["cond"][0], num_timesteps=sc.num_timesteps,
             timestep_shift=sc.timestep_shift, cfg_renorm_min=sc.cfg_renorm_min,
             cfg_renorm_type=sc.cfg_renorm_type, cfg_interval=sc.cfg_interval,
             cfg_text_scale=sc.cfg_text_scale, cfg_img_scale=sc.cfg_img_scale, trace=trace,
-            max_steps=max_steps, **self.cfg_kwargs(), **gi)
+            max_steps=max_steps, enable_taylorseer=sc.enable_taylorseer, teacher_x=teacher_x, **self.cfg_kwargs(), **gi)

@@ -37,6 +37,7 @@ class Scenario:
     cfg_renorm_type: str = "global"
     weight_seed: int = 0
     noise_seed: int = 42
+    enable_taylorseer: bool = False      # TaylorSeer step skipping (modeling/cache_utils/taylorseer.py)
     max_steps: Optional[int] = None      # record/run only the first steps (big shapes)
     slow: bool = False                   # too heavy for the CPU checker inside the default test run
 
@@ -75,6 +76,13 @@ SCENARIOS = {s.name: s for s in [
     Scenario("c1_0p5b_256", BagelDims(hidden_size=896, intermediate_size=4864, num_layers=24, num_heads=14,
                                        num_kv_heads=2, vocab_size=2048),
              [(256, 256)], [16], None, [16], num_timesteps=10, slow=True),
+]}
+
+
+# TaylorSeer step skipping (kept apart: its steps are not independent, so it is checked through generate_image)
+TAYLOR_SCENARIOS = {s.name: s for s in [
+    # steps 0-4 full, then one full step in three; the CFG interval ends at step 11
+    Scenario("tiny_taylor", tiny_dims(2), [(128, 192)], [9], None, [9], num_timesteps=14, enable_taylorseer=True),
 ]}
 
 

@@ -89,8 +89,11 @@ def test_api_errors():
     from tests.gpu_common import gpu_model
     model = gpu_model(sc, run.sd)
     gi = dict(run.gi)
-    with pytest.raises(NotImplementedError):
-        model.generate_image(past_key_values=None, enable_taylorseer=True, **gi)
+    # TaylorSeer needs the CFG branches to start at step 0 (one skip schedule for the packed forward)
+    import dataclasses
+    late = dataclasses.replace(sc, cfg_interval=(0.0, 0.9), enable_taylorseer=True)
+    with pytest.raises(NotImplementedError, match="TaylorSeer"):
+        run_scenario_on_gpu(late, run)
     bad = dict(gi)
     bad["packed_vae_token_indexes"] = gi["packed_vae_token_indexes"].flip(0)
     with pytest.raises(NotImplementedError):
@@ -189,3 +192,43 @@ def test_inferencer_text_to_image_end_to_end():
     p = 10 * np.log10(255.0 ** 2 / max(mse, 1e-12))
     print(f"end-to-end T2I image PSNR vs reference pipeline: {p:.1f} dB")
     assert p >= 40.0
+
+
+def test_taylorseer_matches_reference():
+    """generate_image(enable_taylorseer=True): full steps 0-4, then one full step in three; skipped steps expand the
+    cached last-layer output.  Teacher-forced from the reference's per-step inputs, branch by branch."""
+    from tests.gpu_common import run_scenario_on_gpu
+    from tests.scenarios import TAYLOR_SCENARIOS
+    sc = TAYLOR_SCENARIOS["tiny_taylor"]
+    g = load_golden(sc.name)
+    n = sc.num_timesteps - 1
+    trace = []
+    run_scenario_on_gpu(sc, OracleRun(sc), trace=trace, teacher_x=[g[f"step{i}.x_t"] for i in range(n)])
+    assert len(trace) == n
+    for i, rec in enumerate(trace):
+        for key in ("v_cond", "v_text", "v_img"):
+            gk = f"step{i}.{key}"
+            assert (key in rec) == (gk in g), (i, key)
+            if key in rec:
+                ma, cos = metrics(rec[key], g[gk])
+                assert ma <= 2.5e-2 and cos >= 0.999, (i, key, ma, cos)
+
+
+def test_taylorseer_skipped_steps_ignore_x_t():
+    """On a skipped step the velocity does not depend on the step's input (the layers are not run)."""
+    import dataclasses
+    from tests.gpu_common import run_scenario_on_gpu
+    from tests.scenarios import TAYLOR_SCENARIOS
+    sc = TAYLOR_SCENARIOS["tiny_taylor"]
+    g = load_golden(sc.name)
+    n = sc.num_timesteps - 1
+    xs = [g[f"step{i}.x_t"] for i in range(n)]
+    run = OracleRun(sc)
+    a, b = [], []
+    run_scenario_on_gpu(sc, run, trace=a, teacher_x=xs)
+    xs2 = [x.clone() for x in xs]
+    xs2[5] = xs2[5] + 1.0                                     # steps 5 and 6 are skipped ones
+    xs2[6] = xs2[6] * -2.0
+    run_scenario_on_gpu(sc, run, trace=b, teacher_x=xs2)
+    for i in range(n):
+        assert torch.equal(a[i]["v_cond"], b[i]["v_cond"]), i

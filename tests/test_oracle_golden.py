@@ -65,3 +65,23 @@ def test_oracle_free_running_final_latent():
     out = OracleRun(sc).generate()
     ma, cos = metrics(torch.cat(list(out)), g["final_latent"])
     assert cos >= 0.999 and ma <= 0.1, (ma, cos)
+
+
+def test_oracle_taylorseer_matches_reference():
+    """generate_image with enable_taylorseer=True (full steps 0-4, then one in three; skipped steps return the Taylor
+    expansion of the last layer's cached output), teacher-forced from the reference's per-step inputs."""
+    from tests.scenarios import TAYLOR_SCENARIOS
+    sc = TAYLOR_SCENARIOS["tiny_taylor"]
+    g = load_golden(sc.name)
+    n = sc.num_timesteps - 1
+    trace = []
+    with torch.no_grad():
+        OracleRun(sc).generate(trace=trace, teacher_x=[g[f"step{i}.x_t"] for i in range(n)])
+    assert len(trace) == n
+    for i, rec in enumerate(trace):
+        for key in ("v_cond", "v_text", "v_img"):
+            gk = f"step{i}.{key}"
+            assert (rec[key] is None) == (gk not in g), (i, key)
+            if rec[key] is not None:
+                ma, cos = metrics(rec[key], g[gk])
+                assert ma <= V_MAX_ABS and cos >= V_COSINE, (i, key, ma, cos)
