@@ -24,8 +24,7 @@ def full():
     torch.cuda.empty_cache()
 
 
-def _flow(model, ctx, cond, empty, x_t, B=1, ts=4.0, is_=1.5, renorm="channel"):
-    res = (1024, 1024)
+def _flow(model, ctx, cond, empty, x_t, B=1, ts=4.0, is_=1.5, renorm="channel", res=(1024, 1024)):
     torch.manual_seed(0)
     gi = model.prepare_vae_latent([ctx] * B, [ctx] * B, [res] * B, IDS)
     gt = model.prepare_vae_latent_cfg([0] * B, [0] * B, [res] * B)
@@ -81,3 +80,22 @@ def test_fullsize_batch_invariance(full):
         cond2.value_cache[l] = torch.cat([cond.value_cache[l], cond.value_cache[l]])
     v2, _ = _flow(model, ctx, cond2, empty, torch.cat([x, x]), B=2)
     assert torch.equal(v2[:Nv], v1) and torch.equal(v2[Nv:], v1)
+
+
+def test_fullsize_ragged_resolution(full):
+    """704 x 1264 -> 44 x 79 = 3476 latent tokens: a row count that is a multiple of neither the GEMM tile nor the
+    attention tile.  Same packing and determinism properties, plus global renorm."""
+    model, dims, ctx, cond, empty = full
+    res = (704, 1264)
+    Nv = (res[0] // 16) * (res[1] // 16)
+    x = torch.randn((Nv, dims.patch_latent_dim), generator=torch.Generator().manual_seed(5))
+    v3, br3 = _flow(model, ctx, cond, empty, x, renorm="global", res=res)
+    v3b, _ = _flow(model, ctx, cond, empty, x, renorm="global", res=res)
+    assert v3.shape == (Nv, dims.patch_latent_dim) and torch.isfinite(v3.float()).all() and torch.equal(v3, v3b)
+    v1, br1 = _flow(model, ctx, cond, empty, x, ts=1.0, is_=1.0, res=res)
+    assert torch.equal(br1["v_cond"], br3["v_cond"]) and torch.equal(br3["v_img"], br3["v_cond"])
+    vc, vt_, vi = (br3[k].float() for k in ("v_cond", "v_text", "v_img"))
+    vtext = vt_ + 4.0 * (vc - vt_)
+    vfull = vi + 1.5 * (vtext - vi)
+    ref = vfull * (vc.norm() / (vfull.norm() + 1e-8)).clamp(0.0, 1.0)
+    assert float((v3.float() - ref).abs().max()) <= 0.05 * float(ref.abs().max())
