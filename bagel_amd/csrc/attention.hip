@@ -163,6 +163,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
     const int key0 = kt * KT;
     const bool tail = key0 + KT > (causal ? t.causal_base + wave * 32 + 1 : kv_len);  // wave-uniform
     if (tail) {
+      // keep this a real branch: without a side effect the compiler turns it into 64 compare-and-select
+      // instructions that every tile executes, and only the last tile of a sample needs them
+      asm volatile("; tail mask");
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
