@@ -46,6 +46,20 @@ struct AttnParams {
 
 constexpr int KT = 64;  // keys per tile
 
+// Single-instruction maxima on MFMA results.  fmaxf() makes the compiler canonicalise each accumulator
+// first (one extra v_max per input: 55 instructions for 32 scores instead of 17); the scores are never
+// signalling NaNs, so the bare instruction is enough.
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
   static_assert(HD == 128 || HD == 64, "head_dim 128 or 64");
@@ -163,9 +177,6 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
     const int key0 = kt * KT;
     const bool tail = key0 + KT > (causal ? t.causal_base + wave * 32 + 1 : kv_len);  // wave-uniform
     if (tail) {
-      // keep this a real branch: without a side effect the compiler turns it into 64 compare-and-select
-      // instructions that every tile executes, and only the last tile of a sample needs them
-      asm volatile("; tail mask");
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -175,10 +186,21 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
         }
     }
     // online softmax: this lane holds 32 of the row's 64 keys, lane^32 the other 32
-    float mx = fmaxf(s[0][0], s[1][0]);
+    // The compiler does not track the MFMA-result read hazard for operands of inline assembly: wait out
+    // the 11 states an 8-pass MFMA needs before a VALU may read its result.  The data dependence through
+    // the operands keeps every later read of the scores behind this point.
+    asm volatile("s_nop 7\n\ts_nop 3" : "+v"(s[0]), "+v"(s[1]));
+    float ma = vmax2(s[0][0], s[0][15]), mb = vmax2(s[1][0], s[1][15]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;  // scale > 0 commutes with max
+    for (int r = 1; r < 15; r += 2) {
+      ma = vmax3(ma, s[0][r], s[0][r + 1]);
+      mb = vmax3(mb, s[1][r], s[1][r + 1]);
+    }
+    float mx = vmax2(ma, mb);
+    // lanes l and l^32 exchange their maxima in one instruction (no LDS round trip)
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+    mx = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * p.scale_log2;  // scale > 0 commutes with max
     // The accumulators are rescaled only when some row of this wave raises its running maximum
     // (alpha == 1 exactly otherwise), which after the first few tiles is rare.
     if (__any(mx > m_run)) {

@@ -26,19 +26,33 @@ def case(name, units, nv, ctx, Hq=28, Hkv=4, D=128, iters=10):
     O = torch.empty_like(Q)
     t = torch.tensor(tiles, dtype=torch.int32, device=dev)
     flops = 4.0 * Hq * D * units * (nv + 2) * (ctx + nv + 2)
-    for _ in range(2):
-        K.varlen_attention(Q, Kw, Vt, O, t, len(tiles), Hq, Hkv, D, S)
-    times = []
-    for _ in range(iters):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        K.varlen_attention(Q, Kw, Vt, O, t, len(tiles), Hq, Hkv, D, S)
-        e1.record()
-        torch.cuda.synchronize()
-        times.append(e0.elapsed_time(e1))
-    times.sort()
-    med = times[len(times) // 2]
-    print(f"{name:24s} median {med:.3f} ms  {flops / med / 1e9:.0f} TFLOP/s  (min {times[0]:.3f} ms)", flush=True)
+    variants = [int(v) for v in os.environ.get("ATTN_VARIANTS", "0").split(",")]
+    setv = getattr(K.lib(), "bagel_set_attn_variant", None)
+    times = {v: [] for v in variants}
+    ref = None
+    for v in variants:
+        if setv is not None:
+            setv(v)
+        for _ in range(2):
+            K.varlen_attention(Q, Kw, Vt, O, t, len(tiles), Hq, Hkv, D, S)
+        if ref is None:
+            ref = O.float().clone()
+        else:
+            print(f"   variant {v} max |diff| vs variant {variants[0]}: {(O.float() - ref).abs().max().item():.3e}")
+    for _ in range(iters):          # variants interleaved round by round in one process
+        for v in variants:
+            if setv is not None:
+                setv(v)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            K.varlen_attention(Q, Kw, Vt, O, t, len(tiles), Hq, Hkv, D, S)
+            e1.record()
+            torch.cuda.synchronize()
+            times[v].append(e0.elapsed_time(e1))
+    for v in variants:
+        ts = sorted(times[v])
+        med = ts[len(ts) // 2]
+        print(f"{name:24s} v{v} median {med:.3f} ms  {flops / med / 1e9:.0f} TFLOP/s  (min {ts[0]:.3f} ms)", flush=True)
 
 
 if __name__ == "__main__":
