@@ -63,6 +63,7 @@ __device__ __forceinline__ float vmax2(float a, float b) {
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
   static_assert(HD == 128 || HD == 64, "head_dim 128 or 64");
+#if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor builtins exist only in the device pass
   constexpr int KS = HD / 16;        // k steps of the score product
   constexpr int DB = HD / 32;        // 32-wide d blocks of the output
   constexpr int K_BYTES = KT * HD * 2, V_BYTES = HD * KT * 2, STAGE = K_BYTES + V_BYTES;
@@ -103,30 +104,34 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
   for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + 16 * ks);
 
   // ---- staging: K tile = 64 rows x HD*2 B, Vt tile = HD rows x 128 B, both in 1-KiB DMA pieces
-  const bf16* kbase = p.K + ((long)kvh * p.S + t.kv_start) * HD;
-  const bf16* vbase = p.Vt + (long)kvh * HD * p.S + t.kv_start;
-  const bf16* k_src[K_IT];
-  const bf16* v_src[V_IT];
+  // K and Vt tiles are fetched through buffer descriptors based at this sample's first key: the address of a
+  // piece is descriptor base + a per-lane 32-bit offset that never changes + a scalar tile offset, so the DMA
+  // instructions need no per-piece vector address arithmetic.
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.K + ((long)kvh * p.S + t.kv_start) * HD), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.Vt + (long)kvh * HD * p.S + t.kv_start), 0, 0x7fffffff, 0x00020000);
+  int k_voff[K_IT], v_voff[V_IT];
 #pragma unroll
   for (int it = 0; it < K_IT; ++it) {
     const int krow = (it * 4 + wave) * K_RPP + lane / K_CH;
-    k_src[it] = kbase + (long)krow * HD + (((lane % K_CH) ^ k_swz(krow)) * 8);
+    k_voff[it] = (krow * HD + (((lane % K_CH) ^ k_swz(krow)) * 8)) * 2;
   }
 #pragma unroll
   for (int it = 0; it < V_IT; ++it) {
     const int vrow = (it * 4 + wave) * 8 + (lane >> 3);
-    v_src[it] = vbase + (long)vrow * p.S + (((lane & 7) ^ ((vrow >> 1) & 7)) * 8);
+    v_voff[it] = (int)(((long)vrow * p.S + (((lane & 7) ^ ((vrow >> 1) & 7)) * 8)) * 2);
   }
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * STAGE;
 #pragma unroll
     for (int it = 0; it < K_IT; ++it)
-      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(k_src[it] + (long)kt * KT * HD),
-                                       LDS_PTR(base + (it * 4 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LDS_PTR(base + (it * 4 + wave) * 1024), 16, k_voff[it],
+                                           kt * (KT * HD * 2), 0, 0);
 #pragma unroll
     for (int it = 0; it < V_IT; ++it)
-      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(v_src[it] + kt * KT),
-                                       LDS_PTR(base + K_BYTES + (it * 4 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LDS_PTR(base + K_BYTES + (it * 4 + wave) * 1024), 16, v_voff[it],
+                                           kt * (KT * 2), 0, 0);
   };
 
   // ---- fragment read offsets
@@ -157,22 +162,28 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
     // fence does not reliably wait for LDS-DMA, so the wait is explicit.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < n_kt) stage(kt + 1, (kt + 1) & 1);
     const char* kb = smem + (kt & 1) * STAGE;
     const char* vb = kb + K_BYTES;
 
     // S^T for two 32-key blocks
     f32x16 s[2];
+    // The first block's K fragments are requested before the next tile's DMA is issued (the compiler keeps
+    // LDS reads and LDS-DMA in program order), so their latency passes under the DMA issue; the second
+    // block's are requested while the first block's products run.
+    bf16x8 kf0[KS], kf1[KS];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int ks = 0; ks < KS; ++ks) kf0[ks] = *(const bf16x8*)(kb + k_off[0] + (((2 * ks + h) ^ k_sw) * 16));
+    if (kt + 1 < n_kt) stage(kt + 1, (kt + 1) & 1);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
+    for (int r = 0; r < 16; ++r) s[0][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(kb + k_off[b] + (((2 * ks + h) ^ k_sw) * 16));
-        s[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[b], 0, 0, 0);
-      }
-    }
+    for (int r = 0; r < 16; ++r) s[1][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kf1[ks] = *(const bf16x8*)(kb + k_off[1] + (((2 * ks + h) ^ k_sw) * 16));
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], s[0], 0, 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], s[1], 0, 0, 0);
     // mask the tail keys of the last tile (raw scores; the softmax scale is folded into the exponent)
     const int key0 = kt * KT;
     const bool tail = key0 + KT > (causal ? t.causal_base + wave * 32 + 1 : kv_len);  // wave-uniform
@@ -259,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
         *(bf16x4*)(op + d * 32 + 8 * g + 4 * h) = o4;
       }
   }
+#endif
 }
 
 extern "C" int bagel_varlen_attention_scaled_bf16(const void* Q, const void* K, const void* Vt, void* O,
@@ -282,6 +294,7 @@ extern "C" int bagel_varlen_attention_scaled_bf16(const void* Q, const void* K, 
   BAGEL_CHECK(head_dim == 128 || head_dim == 64, "bagel_varlen_attention_bf16: head_dim %d not supported (128 or 64)", head_dim);
   BAGEL_CHECK(n_tiles > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "bagel_varlen_attention_bf16: bad head counts");
   BAGEL_CHECK(S > 0 && S % 64 == 0, "bagel_varlen_attention_bf16: S=%ld must be a positive multiple of 64", S);
+  BAGEL_CHECK(S * head_dim * 2 < (1L << 31), "bagel_varlen_attention_bf16: S=%ld key slots exceed the 31-bit tile offsets", S);
   BAGEL_CHECK(((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O | (uintptr_t)tiles) % 16 == 0,
               "bagel_varlen_attention_bf16: misaligned operand");
   AttnParams p;

@@ -26,33 +26,44 @@ def case(name, units, nv, ctx, Hq=28, Hkv=4, D=128, iters=10):
     O = torch.empty_like(Q)
     t = torch.tensor(tiles, dtype=torch.int32, device=dev)
     flops = 4.0 * Hq * D * units * (nv + 2) * (ctx + nv + 2)
-    variants = [int(v) for v in os.environ.get("ATTN_VARIANTS", "0").split(",")]
-    setv = getattr(K.lib(), "bagel_set_attn_variant", None)
+    # A/B in one process: "lib" is the library in the tree; ATTN_AB_LIB names another build of the same entry
+    # point (e.g. the previous commit's kernel compiled to tools/_ab/), run round by round beside it.
+    variants = ["lib"]
+    alt = os.environ.get("ATTN_AB_LIB")
+    if alt:
+        import ctypes
+        alt_lib = ctypes.CDLL(os.path.abspath(alt))
+        variants.append("alt")
+
+    def run(v):
+        if v == "lib":
+            K.varlen_attention(Q, Kw, Vt, O, t, len(tiles), Hq, Hkv, D, S)
+        else:
+            rc = alt_lib.bagel_varlen_attention_bf16(K._p(Q), K._p(Kw), K._p(Vt), K._p(O), K._p(t), K.I(len(tiles)), K.I(Hq),
+                                                     K.I(Hkv), K.I(D), K.L(S), K._stream())
+            assert rc == 0
+
     times = {v: [] for v in variants}
     ref = None
     for v in variants:
-        if setv is not None:
-            setv(v)
         for _ in range(2):
-            K.varlen_attention(Q, Kw, Vt, O, t, len(tiles), Hq, Hkv, D, S)
+            run(v)
         if ref is None:
             ref = O.float().clone()
         else:
             print(f"   variant {v} max |diff| vs variant {variants[0]}: {(O.float() - ref).abs().max().item():.3e}")
     for _ in range(iters):          # variants interleaved round by round in one process
         for v in variants:
-            if setv is not None:
-                setv(v)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            K.varlen_attention(Q, Kw, Vt, O, t, len(tiles), Hq, Hkv, D, S)
+            run(v)
             e1.record()
             torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1))
     for v in variants:
         ts = sorted(times[v])
         med = ts[len(ts) // 2]
-        print(f"{name:24s} v{v} median {med:.3f} ms  {flops / med / 1e9:.0f} TFLOP/s  (min {ts[0]:.3f} ms)", flush=True)
+        print(f"{name:24s} {v} median {med:.3f} ms  {flops / med / 1e9:.0f} TFLOP/s  (min {ts[0]:.3f} ms)", flush=True)
 
 
 if __name__ == "__main__":
