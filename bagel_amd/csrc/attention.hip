@@ -21,6 +21,7 @@
 // Arithmetic follows FlashAttention-2: fp32 scores and statistics, P rounded to bf16 for P.V,
 // fp32 accumulation, division by the fp32 row sum at the end.
 #include "common.h"
+#include <type_traits>
 
 struct AttnTile {
   int q_row0;       // first query row (row index into Q / O)
@@ -157,12 +158,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
   const int row_limit = causal ? t.causal_base + wave * 32 + l31 + 1 : kv_len;  // keys this lane's row may see
   const int n_kt = (kv_len + KT - 1) / KT;
   stage(0, 0);
-  for (int kt = 0; kt < n_kt; ++kt) {
+  // One 64-key tile.  BUF (the LDS buffer the tile sits in) is a compile-time constant, so every fragment
+  // address is a loop-invariant register plus an immediate; the loop below alternates the two instances.
+  auto tile_step = [&](const int kt, auto buf_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;
     // The LDS-DMA of tile kt must have landed before the barrier publishes it: the compiler's barrier
     // fence does not reliably wait for LDS-DMA, so the wait is explicit.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const char* kb = smem + (kt & 1) * STAGE;
+    const char* kb = smem + BUF * STAGE;
     const char* vb = kb + K_BYTES;
 
     // S^T for two 32-key blocks
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
     bf16x8 kf0[KS], kf1[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) kf0[ks] = *(const bf16x8*)(kb + k_off[0] + (((2 * ks + h) ^ k_sw) * 16));
-    if (kt + 1 < n_kt) stage(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < n_kt) stage(kt + 1, BUF ^ 1);
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[0][r] = 0.f;
 #pragma unroll
@@ -252,6 +256,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
           o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[d], 0, 0, 0);
         }
       }
+  };
+  for (int kt = 0; kt < n_kt; kt += 2) {
+    tile_step(kt, std::integral_constant<int, 0>{});
+    if (kt + 1 < n_kt) tile_step(kt + 1, std::integral_constant<int, 1>{});
   }
 
   // ---- epilogue: lane holds query row l31, d = db*32 + (r&3) + 8*(r>>2) + 4h
