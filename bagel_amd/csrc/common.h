@@ -17,9 +17,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 __device__ __forceinline__ float round_bf16(float x) { return (float)(bf16)x; }
 
 // torch GELU(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+// (0.5 (1 + tanh u) = sigmoid(2u): one exponential and one hardware reciprocal instead of the library tanhf)
 __device__ __forceinline__ float gelu_tanh_f32(float x) {
   const float inner = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return 0.5f * x * (1.f + tanhf(inner));
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * inner));
 }
 
 // x * sigmoid(x).  The hardware reciprocal (1 ulp) replaces the IEEE division's ten-instruction sequence: the
