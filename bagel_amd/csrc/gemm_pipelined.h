@@ -27,7 +27,7 @@
 // exist because the tile count should be a whole number of 256-CU rounds: with 12288 rows, N = 3584 is
 // 2.6 rounds of 256-wide tiles but exactly 3 rounds of 224-wide ones, N = 4608 is 3.4 rounds of 256-wide
 // tiles but exactly 3 of 288-wide ones.
-template <int EPI, int BN, int WR>
+template <int EPI, int BN, int WR, bool LEAD = false>
 __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
   constexpr int BM = 256, NW = 8, WC = NW / WR, TM = BM / WR, TN = BN / WC, FM = TM / 16, FN = TN / 16, FH = FM / 2;
   static_assert(TN % 16 == 0 && FM % 2 == 0 && BN % 8 == 0, "wave tile must be whole 16x16 fragments");
@@ -35,6 +35,7 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
   constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES, STAGE_BYTES = A_BYTES + W_BYTES;
   constexpr int W_PIECES = BN / 8, W_ITERS = (W_PIECES + NW - 1) / NW;  // 1-KiB DMA pieces of the W tile
   constexpr bool W_EVEN = W_PIECES % NW == 0;
+#if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor builtins exist only in the device pass
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -46,10 +47,11 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
   const int ntiles = p.tiles_m * p.tiles_n;
   const int piece_row = lane >> 3;
   const int src_chunk = (lane & 7) ^ piece_row;
+  int m0, n0;
+  // ---- even split (LEAD false): every wave stages an eighth of each tile
   const bf16* a_src[4];
   const bf16* w_src[W_ITERS];
-  int m0, n0;
-  auto set_tile = [&](int t) {
+  auto set_tile_even = [&](int t) {
     int tile_m, tile_n;
     gemm_tile_of_block(p, t, tile_m, tile_n);
     m0 = tile_m * BM;
@@ -65,19 +67,91 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
       w_src[it] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + src_chunk * 8;
     }
   };
-  auto stage_a = [&](int kt) {
+  auto stage_a_even = [&](int kt) {
     char* base = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
     for (int it = 0; it < 4; ++it)
       __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a_src[it] + kt * BK), LDS_PTR(base + (it * NW + wave) * 1024), 16, 0, 0);
   };
-  auto stage_w = [&](int kt) {
+  auto stage_w_even = [&](int kt) {
     char* base = smem + (kt & 1) * STAGE_BYTES + A_BYTES;
 #pragma unroll
     for (int it = 0; it < W_ITERS; ++it)
       if (W_EVEN || it + 1 < W_ITERS || it * NW + wave < W_PIECES)  // wave-uniform
         __builtin_amdgcn_global_load_lds(GLOBAL_PTR(w_src[it] + kt * BK), LDS_PTR(base + (it * NW + wave) * 1024), 16, 0, 0);
   };
+
+  // ---- leading-wave split (LEAD true)
+  // DMA pieces are dealt unevenly.  Waves w and w + 4 share a SIMD, and the older one (w < 4) wins the MFMA
+  // arbitration, runs ahead and then idles at the K step's barrier while the younger one finishes alone:
+  // every cycle the younger wave spends issuing DMA is then a cycle with an empty matrix pipe.  So the
+  // leading waves issue (LEAD ? 8 : 4)/8 of the pieces.
+  // Pieces are fetched through buffer descriptors based at the tile's first row (address = base + a per-lane
+  // 32-bit offset fixed for the tile + a scalar K offset), which keeps a piece at one register.
+  constexpr int A_PIECES = BM / 8;
+  constexpr int LA = A_PIECES * (LEAD ? 8 : 4) / 8 / 4, TA = (A_PIECES - 4 * LA) / 4;                // per leading / trailing wave
+  constexpr int LW = (W_PIECES * (LEAD ? 8 : 4) / 8 + 3) / 4, TW = (W_PIECES - 4 * LW + 3) / 4 > 0 ? (W_PIECES - 4 * LW + 3) / 4 : 0;
+  constexpr int NA = LA > TA ? LA : TA, NWI = LW > TW ? LW : TW;
+  const bool lead = wave < 4;
+  auto a_piece = [&](int it) { return lead ? (it < LA ? it * 4 + wave : -1) : (it < TA ? LA * 4 + it * 4 + wave - 4 : -1); };
+  auto w_piece = [&](int it) {
+    const int pc = lead ? (it < LW ? it * 4 + wave : -1) : (it < TW ? LW * 4 + it * 4 + wave - 4 : -1);
+    return pc < W_PIECES ? pc : -1;
+  };
+  __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
+  int a_voff[NA], w_voff[NWI];
+  auto set_tile_lead = [&](int t) {
+    int tile_m, tile_n;
+    gemm_tile_of_block(p, t, tile_m, tile_n);
+    m0 = tile_m * BM;
+    n0 = tile_n * BN;
+    a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long)m0 * p.lda), 0, 0x7fffffff, 0x00020000);
+    w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int row = max(a_piece(it), 0) * 8 + piece_row;
+      a_voff[it] = (int)(((long)min(row, p.M - 1 - m0) * p.lda + src_chunk * 8) * 2);
+    }
+#pragma unroll
+    for (int it = 0; it < NWI; ++it) {
+      const int row = max(w_piece(it), 0) * 8 + piece_row;
+      w_voff[it] = (int)(((long)min(row, p.N - 1 - n0) * p.ldw + src_chunk * 8) * 2);
+    }
+  };
+  auto stage_a_lead = [&](int kt) {
+    char* base = smem + (kt & 1) * STAGE_BYTES;
+    if (lead) {  // wave-uniform
+#pragma unroll
+      for (int it = 0; it < LA; ++it)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, LDS_PTR(base + (it * 4 + wave) * 1024), 16, a_voff[it],
+                                                 kt * (BK * 2), 0, 0);
+    } else {
+#pragma unroll
+      for (int it = 0; it < TA; ++it)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, LDS_PTR(base + (LA * 4 + it * 4 + wave - 4) * 1024), 16,
+                                                 a_voff[it], kt * (BK * 2), 0, 0);
+    }
+  };
+  auto stage_w_lead = [&](int kt) {
+    char* base = smem + (kt & 1) * STAGE_BYTES + A_BYTES;
+    if (lead) {
+#pragma unroll
+      for (int it = 0; it < LW; ++it)
+        if (it * 4 + 3 < W_PIECES || it * 4 + wave < W_PIECES)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, LDS_PTR(base + (it * 4 + wave) * 1024), 16, w_voff[it],
+                                                   kt * (BK * 2), 0, 0);
+    } else {
+#pragma unroll
+      for (int it = 0; it < TW; ++it)
+        if (LW * 4 + it * 4 + 3 < W_PIECES || LW * 4 + it * 4 + wave - 4 < W_PIECES)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, LDS_PTR(base + (LW * 4 + it * 4 + wave - 4) * 1024), 16,
+                                                   w_voff[it], kt * (BK * 2), 0, 0);
+    }
+  };
+
+  auto set_tile = [&](int t) { if constexpr (LEAD) set_tile_lead(t); else set_tile_even(t); };
+  auto stage_a = [&](int kt) { if constexpr (LEAD) stage_a_lead(kt); else stage_a_even(kt); };
+  auto stage_w = [&](int kt) { if constexpr (LEAD) stage_w_lead(kt); else stage_w_even(kt); };
 
   const int frow = lane & 15, fq = lane >> 4;
   int a_off[2], w_off[2];
@@ -173,4 +247,5 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
     if (tn >= ntiles) break;
     t = tn;
   }
+#endif
 }

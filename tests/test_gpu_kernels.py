@@ -323,3 +323,37 @@ def test_gemm_tile_variants(variant, M, N, K, epi):
     finally:
         lib.bagel_set_gemm_variant(-1)
     _close(C, ref, ulps=3.0, what=f"variant {variant} {epi}")
+
+
+@pytest.mark.parametrize("variant", [3, 4, 5, 6])
+@pytest.mark.parametrize("M,N,K,epi", [(700, 512, 256, "bias"), (300, 1024, 320, "swiglu"), (1030, 3584, 8192, "residual")])
+def test_gemm_dma_split_is_invisible(variant, M, N, K, epi):
+    """The pipelined tiles stage their operands either an eighth per wave or all on the four leading waves
+    (chosen by K); both must give the same bits, ragged M and N included."""
+    k = _K()
+    lib = k.lib()
+    if epi == "swiglu" and variant in (4, 5):
+        pytest.skip("this tile shape has no SwiGLU epilogue")
+    A, W = _rand((M, K), 1.0, 80).to(DEV), _rand((N, K), 0.05, 81).to(DEV)
+    b = _rand((N,), 0.5, 82).to(DEV)
+    R = _rand((M, N), 1.0, 83).to(DEV)
+    outs = []
+    lib.bagel_set_gemm_variant(variant)
+    try:
+        for lead in (0, 1):
+            lib.bagel_set_gemm_lead(lead)
+            if epi == "bias":
+                C = torch.full((M, N), float("nan"), dtype=BF16, device=DEV)
+                k.gemm(A, W, C, bias=b)
+            elif epi == "residual":
+                C = R.clone()
+                k.gemm(A, W, C, residual=C, epilogue=k.EPI_RESIDUAL)
+            else:
+                C = torch.full((M, N // 2), float("nan"), dtype=BF16, device=DEV)
+                k.gemm(A, W, C, epilogue=k.EPI_SWIGLU)
+            outs.append(C.clone())
+    finally:
+        lib.bagel_set_gemm_variant(-1)
+        lib.bagel_set_gemm_lead(-1)
+    assert not torch.isnan(outs[0].float()).any()
+    assert torch.equal(outs[0], outs[1])
