@@ -99,3 +99,55 @@ def test_fullsize_ragged_resolution(full):
     vfull = vi + 1.5 * (vtext - vi)
     ref = vfull * (vc.norm() / (vfull.norm() + 1e-8)).clamp(0.0, 1.0)
     assert float((v3.float() - ref).abs().max()) <= 0.05 * float(ref.abs().max())
+
+
+def _flow3(model, x_t, caches, lens, ts=4.0, is_=1.5, renorm="global", res=(1024, 1024)):
+    """One flow step with a different context (cache, length) for each of cond / text-uncond / img-uncond."""
+    torch.manual_seed(0)
+    (c_cond, c_text, c_img), (n_cond, n_text, n_img) = caches, lens
+    gi = model.prepare_vae_latent([n_cond], [n_cond], [res], IDS)
+    gt = model.prepare_vae_latent_cfg([n_text], [n_text], [res])
+    gm = model.prepare_vae_latent_cfg([n_img], [n_img], [res])
+    gi.pop("packed_init_noises")
+    v = model._forward_flow(
+        x_t=x_t, timestep=torch.full((x_t.shape[0],), 0.7), past_key_values=c_cond, cfg_renorm_min=0.0,
+        cfg_renorm_type=renorm, cfg_text_scale=ts, cfg_text_packed_position_ids=gt["cfg_packed_position_ids"],
+        cfg_text_packed_query_indexes=gt["cfg_packed_query_indexes"], cfg_text_key_values_lens=gt["cfg_key_values_lens"],
+        cfg_text_past_key_values=c_text, cfg_text_packed_key_value_indexes=gt["cfg_packed_key_value_indexes"],
+        cfg_img_scale=is_, cfg_img_packed_position_ids=gm["cfg_packed_position_ids"],
+        cfg_img_packed_query_indexes=gm["cfg_packed_query_indexes"], cfg_img_key_values_lens=gm["cfg_key_values_lens"],
+        cfg_img_past_key_values=c_img, cfg_img_packed_key_value_indexes=gm["cfg_packed_key_value_indexes"], **gi)
+    return v.clone(), {k: (None if t is None else t.clone()) for k, t in model.last_step_velocities.items()}
+
+
+def test_fullsize_edit_contexts(full):
+    """The editing shape: three branches with contexts of 9034 / 9000 / 34 tokens (13 k keys per query tile).
+    Determinism; every branch equals itself run with the other two contexts swapped for short ones (packing);
+    and non-causal attention does not care about the ORDER of the context tokens: the same context with its
+    tokens permuted gives the same velocity up to accumulation order (cosine >= 0.999, the parity bar)."""
+    from bench import synthetic_context
+    from bagel_amd.modeling import NaiveCache
+    model, dims, ctx, cond34, empty = full
+    dev = torch.device(DEV)
+    long_a = synthetic_context(dims, 1, 9034, dev, 11)
+    long_b = synthetic_context(dims, 1, 9000, dev, 12)
+    Nv = 4096
+    x = torch.randn((Nv, dims.patch_latent_dim), generator=torch.Generator().manual_seed(6))
+    v, br = _flow3(model, x, (long_a, long_b, cond34), (9034, 9000, 34))
+    assert torch.isfinite(v.float()).all() and 0.05 < float(v.float().std()) < 50
+    v_again, br_again = _flow3(model, x, (long_a, long_b, cond34), (9034, 9000, 34))
+    assert torch.equal(v, v_again) and all(torch.equal(br[k], br_again[k]) for k in br)
+    # packing: the cond branch (9034 keys) does not depend on what the other two branches attend to
+    _, br_short = _flow3(model, x, (long_a, empty, cond34), (9034, 0, 34))
+    assert torch.equal(br_short["v_cond"], br["v_cond"]) and torch.equal(br_short["v_img"], br["v_img"])
+    # key order: permute the context tokens of the cond branch (K and V rows together)
+    perm = torch.randperm(9034, generator=torch.Generator().manual_seed(7)).to(dev)
+    shuffled = NaiveCache(dims.num_layers)
+    for l in range(dims.num_layers):
+        shuffled.key_cache[l] = long_a.key_cache[l][perm].contiguous()
+        shuffled.value_cache[l] = long_a.value_cache[l][perm].contiguous()
+    _, br_perm = _flow3(model, x, (shuffled, long_b, cond34), (9034, 9000, 34))
+    a, b = br["v_cond"].float().flatten(), br_perm["v_cond"].float().flatten()
+    cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+    assert cos >= 0.999, cos
+    assert torch.equal(br_perm["v_text"], br["v_text"])   # the other branches never saw the permutation
