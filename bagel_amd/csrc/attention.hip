@@ -64,8 +64,13 @@ __device__ __forceinline__ float vmax2(float a, float b) {
   return r;
 }
 
-template <int HD>
-__global__ __launch_bounds__(256, 3) void attention_kernel(AttnParams p) {
+// DEEP = false: the layout described above (one K and one Vt buffer, two barriers per tile, three workgroups per
+// CU) - the throughput form, used whenever the launch can fill the chip.
+// DEEP = true: two K and two Vt buffers, the whole next tile in flight behind the current one and one barrier
+// per tile - the latency form for launches of at most two workgroups per CU (a decode step, the vision
+// tower on one image), where nothing else on the CU would cover the DMA latency the single buffers expose.
+template <int HD, bool DEEP>
+__global__ __launch_bounds__(256, DEEP ? 2 : 3) void attention_kernel(AttnParams p) {
   static_assert(HD == 128 || HD == 64, "head_dim 128 or 64");
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor builtins exist only in the device pass
   constexpr int KS = HD / 16;        // k steps of the score product
@@ -126,15 +131,15 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(AttnParams p) {
     const int vrow = (it * 4 + wave) * 8 + (lane >> 3);
     v_voff[it] = (int)(((long)vrow * p.S + (((lane & 7) ^ ((vrow >> 1) & 7)) * 8)) * 2);
   }
-  auto stage_k = [&](int kt) {
-    char* base = smem;
+  auto stage_k = [&](int kt, int buf) {
+    char* base = smem + buf * STAGE;
 #pragma unroll
     for (int it = 0; it < K_IT; ++it)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LDS_PTR(base + (it * 4 + wave) * 1024), 16, k_voff[it],
                                                kt * (KT * HD * 2), 0, 0);
   };
-  auto stage_v = [&](int kt) {
-    char* base = smem + K_BYTES;
+  auto stage_v = [&](int kt, int buf) {
+    char* base = smem + buf * STAGE + K_BYTES;
 #pragma unroll
     for (int it = 0; it < V_IT; ++it)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LDS_PTR(base + (it * 4 + wave) * 1024), 16, v_voff[it],
@@ -163,10 +168,11 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(AttnParams p) {
   const int kv_len = causal ? min(t.kv_len, t.causal_base + t.n_rows) : t.kv_len;
   const int row_limit = causal ? t.causal_base + wave * 32 + l31 + 1 : kv_len;  // keys this lane's row may see
   const int n_kt = (kv_len + KT - 1) / KT;
-  stage_k(0);
-  const char* kb = smem;
-  const char* vb = smem + K_BYTES;
+  stage_k(0, 0);
+  if constexpr (DEEP) stage_v(0, 0);
   for (int kt = 0; kt < n_kt; ++kt) {
+    const char* kb = smem + (DEEP ? (kt & 1) * STAGE : 0);
+    const char* vb = kb + K_BYTES;
     // The LDS-DMA of this tile's keys must have landed before the barrier publishes it: the compiler's
     // barrier fence does not wait for LDS-DMA, so the wait is explicit.  The barrier also says that every
     // wave is done with the previous tile's values.
@@ -181,7 +187,14 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(AttnParams p) {
     bf16x8 kf0[KS], kf1[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) kf0[ks] = *(const bf16x8*)(kb + k_off[0] + (((2 * ks + h) ^ k_sw) * 16));
-    stage_v(kt);
+    if constexpr (DEEP) {
+      if (kt + 1 < n_kt) {
+        stage_k(kt + 1, (kt + 1) & 1);
+        stage_v(kt + 1, (kt + 1) & 1);
+      }
+    } else {
+      stage_v(kt, 0);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[0][r] = 0.f;
 #pragma unroll
@@ -233,10 +246,12 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
     }
-    // this tile's values have landed and every wave is done with its keys
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < n_kt) stage_k(kt + 1);
+    if constexpr (!DEEP) {
+      // this tile's values have landed and every wave is done with its keys
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < n_kt) stage_k(kt + 1, 0);
+    }
     const float neg_m = m_run == -INFINITY ? 0.f : -m_run;
     float psum = 0.f;
 #pragma unroll
@@ -288,6 +303,9 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(AttnParams p) {
 extern "C" int bagel_varlen_attention_scaled_bf16(const void* Q, const void* K, const void* Vt, void* O,
                                                   const void* tiles, int n_tiles, int Hq, int Hkv, int head_dim,
                                                   long S, float softmax_scale, void* stream);
+// Development knob: -1 automatic (by launch size), 0 / 1 force the throughput / latency form of the kernel.
+static int g_attn_deep = -1;
+extern "C" void bagel_set_attn_deep(int v) { g_attn_deep = v; }
 
 extern "C" int bagel_varlen_attention_bf16(const void* Q, const void* K, const void* Vt, void* O,
                                            const void* tiles, int n_tiles, int Hq, int Hkv, int head_dim,
@@ -313,11 +331,29 @@ extern "C" int bagel_varlen_attention_scaled_bf16(const void* Q, const void* K, 
   p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.Vt = (const bf16*)Vt; p.O = (bf16*)O;
   p.tiles = (const AttnTile*)tiles; p.n_tiles = n_tiles; p.Hq = Hq; p.Hkv = Hkv; p.S = S;
   p.scale_log2 = 1.4426950408889634f * softmax_scale;
-  const size_t lds = (size_t)KT * head_dim * 2 * 2;  // one K tile + one Vt tile
-  if (head_dim == 128)
-    hipLaunchKernelGGL(attention_kernel<128>, dim3(n_tiles * Hq), dim3(256), lds, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL(attention_kernel<64>, dim3(n_tiles * Hq), dim3(256), lds, (hipStream_t)stream, p);
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  const bool deep = g_attn_deep >= 0 ? g_attn_deep != 0 : (long)n_tiles * Hq <= 2L * cus;
+  const size_t tile_pair = (size_t)KT * head_dim * 2 * 2;  // one K tile + one Vt tile
+  const size_t lds = deep ? 2 * tile_pair : tile_pair;
+  if (head_dim == 128) {
+    static bool configured = false;
+    if (!configured) {
+      (void)hipFuncSetAttribute((const void*)attention_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * KT * 128 * 2 * 2);
+      configured = true;
+    }
+    if (deep) hipLaunchKernelGGL((attention_kernel<128, true>), dim3(n_tiles * Hq), dim3(256), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attention_kernel<128, false>), dim3(n_tiles * Hq), dim3(256), lds, (hipStream_t)stream, p);
+  } else {
+    if (deep) hipLaunchKernelGGL((attention_kernel<64, true>), dim3(n_tiles * Hq), dim3(256), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attention_kernel<64, false>), dim3(n_tiles * Hq), dim3(256), lds, (hipStream_t)stream, p);
+  }
   BAGEL_LAUNCH_CHECK();
   return 0;
 }

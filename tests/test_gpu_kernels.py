@@ -159,8 +159,10 @@ def test_qk_norm_rope_kv(und_rounding):
     assert float(Kws.cpu()[:, untouched].abs().max()) == 0.0 and float(Vt.cpu()[:, :, untouched].abs().max()) == 0.0
 
 
-def _attention_case(q_lens, ctx_lens, Hq, Hkv, seed, spike=False, causal=False, D=128):
-    """Build Q and a KV workspace with per-sample [context | queries] ranges and the tile table."""
+def _attention_case(q_lens, ctx_lens, Hq, Hkv, seed, spike=False, causal=False, D=128, form=-1):
+    """Build Q and a KV workspace with per-sample [context | queries] ranges and the tile table.
+    ``form``: -1 lets the launcher choose by launch size, 0 / 1 force the kernel's throughput form (single LDS
+    buffers, three workgroups per CU) / latency form (double buffers)."""
     k = _K()
     g = torch.Generator().manual_seed(seed)
     M = sum(q_lens)
@@ -181,8 +183,12 @@ def _attention_case(q_lens, ctx_lens, Hq, Hkv, seed, spike=False, causal=False, 
             tiles.append((r0 + q0, min(128, n - q0), st, kl, (kl - n + q0) if causal else -1, 0, 0, 0))
         r0 += n
     Od = torch.full((M, Hq, D), float("nan"), dtype=BF16, device=DEV)
-    k.varlen_attention(Q.to(DEV), Kf.to(DEV), Vf.permute(0, 2, 1).contiguous().to(DEV), Od,
-                       torch.tensor(tiles, dtype=torch.int32).to(DEV), len(tiles), Hq, Hkv, D, S)
+    k.lib().bagel_set_attn_deep(form)
+    try:
+        k.varlen_attention(Q.to(DEV), Kf.to(DEV), Vf.permute(0, 2, 1).contiguous().to(DEV), Od,
+                           torch.tensor(tiles, dtype=torch.int32).to(DEV), len(tiles), Hq, Hkv, D, S)
+    finally:
+        k.lib().bagel_set_attn_deep(-1)
     kk = torch.cat([Kf[:, st:st + kl].permute(1, 0, 2) for st, kl in zip(starts, kv_lens)])
     vv = torch.cat([Vf[:, st:st + kl].permute(1, 0, 2) for st, kl in zip(starts, kv_lens)])
     ref = O.varlen_attention(Q, kk, vv, q_lens, kv_lens, causal=causal)
@@ -191,30 +197,41 @@ def _attention_case(q_lens, ctx_lens, Hq, Hkv, seed, spike=False, causal=False, 
 
 @pytest.mark.parametrize("q_lens,ctx_lens,Hq,Hkv", [
     ([128], [0], 2, 1), ([2], [62], 2, 1), ([66, 130], [7, 300], 4, 2), ([258], [34], 14, 2), ([1026], [4100], 7, 1)])
-def test_varlen_attention(q_lens, ctx_lens, Hq, Hkv):
-    got, ref = _attention_case(q_lens, ctx_lens, Hq, Hkv, seed=40)
+@pytest.mark.parametrize("form", [0, 1])
+def test_varlen_attention(q_lens, ctx_lens, Hq, Hkv, form):
+    got, ref = _attention_case(q_lens, ctx_lens, Hq, Hkv, seed=40, form=form)
     assert not torch.isnan(got.float()).any()
     _close(got, ref, ulps=2.0, what="attention")
 
 
 @pytest.mark.parametrize("q_lens,ctx_lens,Hq,Hkv", [([34], [0], 2, 1), ([5, 200], [0, 77], 4, 2), ([300], [130], 14, 2)])
-def test_varlen_attention_causal(q_lens, ctx_lens, Hq, Hkv):
-    got, ref = _attention_case(q_lens, ctx_lens, Hq, Hkv, seed=42, causal=True)
+@pytest.mark.parametrize("form", [0, 1])
+def test_varlen_attention_causal(q_lens, ctx_lens, Hq, Hkv, form):
+    got, ref = _attention_case(q_lens, ctx_lens, Hq, Hkv, seed=42, causal=True, form=form)
     assert not torch.isnan(got.float()).any()
     _close(got, ref, ulps=2.0, what="causal attention")
 
 
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("q_lens,ctx_lens,Hq,Hkv", [([258], [18], 14, 2), ([2, 70], [0, 129], 4, 2)])
-def test_varlen_attention_head_dim_64(q_lens, ctx_lens, Hq, Hkv, causal):
-    got, ref = _attention_case(q_lens, ctx_lens, Hq, Hkv, seed=43, causal=causal, D=64)
+@pytest.mark.parametrize("form", [0, 1])
+def test_varlen_attention_head_dim_64(q_lens, ctx_lens, Hq, Hkv, causal, form):
+    got, ref = _attention_case(q_lens, ctx_lens, Hq, Hkv, seed=43, causal=causal, D=64, form=form)
     assert not torch.isnan(got.float()).any()
     _close(got, ref, ulps=2.0, what="attention D=64")
 
 
-def test_varlen_attention_running_max_jump():
-    got, ref = _attention_case([130], [500], 2, 1, seed=41, spike=True)
+@pytest.mark.parametrize("form", [0, 1])
+def test_varlen_attention_running_max_jump(form):
+    got, ref = _attention_case([130], [500], 2, 1, seed=41, spike=True, form=form)
     _close(got, ref, ulps=2.0, what="attention spike")
+
+
+def test_varlen_attention_forms_agree():
+    """Both forms walk the same tiles in the same order: identical bits."""
+    a, _ = _attention_case([66, 130], [7, 300], 4, 2, seed=44, form=0)
+    b, _ = _attention_case([66, 130], [7, 300], 4, 2, seed=44, form=1)
+    assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("renorm,use_img,rmin", [("global", True, 0.0), ("global", False, 0.0), ("channel", True, 0.0),
