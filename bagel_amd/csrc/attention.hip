@@ -342,12 +342,8 @@ extern "C" int bagel_varlen_attention_scaled_bf16(const void* Q, const void* K, 
   const size_t tile_pair = (size_t)KT * head_dim * 2 * 2;  // one K tile + one Vt tile
   const size_t lds = deep ? 2 * tile_pair : tile_pair;
   if (head_dim == 128) {
-    static bool configured = false;
-    if (!configured) {
-      (void)hipFuncSetAttribute((const void*)attention_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * KT * 128 * 2 * 2);
-      configured = true;
-    }
+    static BagelLdsAllowed allowed;
+    bagel_allow_lds(allowed, (const void*)attention_kernel<128, true>, 2 * KT * 128 * 2 * 2);
     if (deep) hipLaunchKernelGGL((attention_kernel<128, true>), dim3(n_tiles * Hq), dim3(256), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attention_kernel<128, false>), dim3(n_tiles * Hq), dim3(256), lds, (hipStream_t)stream, p);
   } else {

@@ -44,6 +44,19 @@ void bagel_set_error(const char* fmt, ...);
     }                                     \
   } while (0)
 
+// Dynamic LDS above 64 KiB has to be allowed per kernel AND per device.  One of these per kernel remembers the
+// devices it has been allowed on (one process normally drives one GPU, but nothing here depends on that).
+struct BagelLdsAllowed {
+  unsigned long long devices = 0;
+};
+inline void bagel_allow_lds(BagelLdsAllowed& st, const void* kernel, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (st.devices & bit) return;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess) st.devices |= bit;
+}
+
 #define BAGEL_LAUNCH_CHECK()                                               \
   do {                                                                     \
     hipError_t e_ = hipGetLastError();                                     \

@@ -50,11 +50,8 @@ static int launch_gemm(GemmParams p, int epilogue, hipStream_t stream) {
 #define LAUNCH(EPI)                                                                              \
   do {                                                                                           \
     auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, EPI, A_DENSE>;                                        \
-    static bool configured = false;                                                              \
-    if (!configured) {                                                                           \
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      configured = true;                                                                         \
-    }                                                                                            \
+    static BagelLdsAllowed allowed;                                                              \
+    bagel_allow_lds(allowed, (const void*)kern, (int)lds);                                       \
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);                                       \
   } while (0)
   switch (epilogue) {
@@ -79,11 +76,8 @@ static int launch_pingpong(GemmParams p, int epilogue, hipStream_t stream) {
 #define LAUNCH(EPI)                                                                              \
   do {                                                                                           \
     auto kern = gemm256_pingpong_kernel<EPI>;                                                    \
-    static bool configured = false;                                                              \
-    if (!configured) {                                                                           \
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      configured = true;                                                                         \
-    }                                                                                            \
+    static BagelLdsAllowed allowed;                                                              \
+    bagel_allow_lds(allowed, (const void*)kern, (int)lds);                                       \
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);                                       \
   } while (0)
   switch (epilogue) {
@@ -115,12 +109,9 @@ static int launch_pipelined(GemmParams p, int epilogue, hipStream_t stream) {
   do {                                                                                           \
     auto k0 = gemm256_pipelined_kernel<EPI, BN, WR, false>;                                    \
     auto k1 = gemm256_pipelined_kernel<EPI, BN, WR, true>;                                     \
-    static bool configured = false;                                                              \
-    if (!configured) {                                                                           \
-      (void)hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      configured = true;                                                                         \
-    }                                                                                            \
+    static BagelLdsAllowed allowed0, allowed1;                                                   \
+    bagel_allow_lds(allowed0, (const void*)k0, (int)lds);                                        \
+    bagel_allow_lds(allowed1, (const void*)k1, (int)lds);                                        \
     hipLaunchKernelGGL(lead ? k1 : k0, grid, block, lds, stream, p);                             \
   } while (0)
   switch (epilogue) {
