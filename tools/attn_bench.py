@@ -29,9 +29,8 @@ def case(name, units, nv, ctx, Hq=28, Hkv=4, D=128, iters=10):
     # A/B in one process: "lib" is the library in the tree; ATTN_AB_LIB names another build of the same entry
     # point (e.g. the previous commit's kernel compiled to tools/_ab/), run round by round beside it.
     variants = ["lib"]
-    setc = getattr(K.lib(), "bagel_set_attn_compact", None)
-    if setc is not None:
-        variants += ["mode1", "mode2"]
+    if os.environ.get("ATTN_FORMS"):   # also time the kernel's two forms explicitly
+        variants += ["throughput", "latency"]
     alt = os.environ.get("ATTN_AB_LIB")
     if alt:
         import ctypes
@@ -39,9 +38,8 @@ def case(name, units, nv, ctx, Hq=28, Hkv=4, D=128, iters=10):
         variants.append("alt")
 
     def run(v):
-        if v in ("lib", "mode1", "mode2"):
-            if setc is not None:
-                setc({"lib": 0, "mode1": 1, "mode2": 2}[v])
+        if v in ("lib", "throughput", "latency"):
+            K.lib().bagel_set_attn_deep({"lib": -1, "throughput": 0, "latency": 1}[v])
             K.varlen_attention(Q, Kw, Vt, O, t, len(tiles), Hq, Hkv, D, S)
         else:
             rc = alt_lib.bagel_varlen_attention_bf16(K._p(Q), K._p(Kw), K._p(Vt), K._p(O), K._p(t), K.I(len(tiles)), K.I(Hq),
