@@ -170,6 +170,27 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 3) void attention_kernel(AttnParams
   const int n_kt = (kv_len + KT - 1) / KT;
   stage_k(0, 0);
   if constexpr (DEEP) stage_v(0, 0);
+  if (wave * 32 >= t.n_rows) {
+    // This wave owns no query row (a two-row tile of special tokens, a one-row decode tile, a ragged last tile):
+    // it only moves its share of the K/V tiles and keeps the barrier count, leaving the SIMD's matrix and
+    // vector issue to the workgroups it shares the CU with.
+    for (int kt = 0; kt < n_kt; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if constexpr (DEEP) {
+        if (kt + 1 < n_kt) {
+          stage_k(kt + 1, (kt + 1) & 1);
+          stage_v(kt + 1, (kt + 1) & 1);
+        }
+      } else {
+        stage_v(kt, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < n_kt) stage_k(kt + 1, 0);
+      }
+    }
+    return;
+  }
   for (int kt = 0; kt < n_kt; ++kt) {
     const char* kb = smem + (DEEP ? (kt & 1) * STAGE : 0);
     const char* vb = kb + K_BYTES;
