@@ -204,7 +204,7 @@ def main():
                                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_hot_kernels_pmc.txt",
                                "kernel": "gemm256_pipelined_kernel<EPI_SWIGLU, 256, 4> (gen-expert gate+up projection)",
                                "launches_timed": len(ms), "avg_launch_ms": avg, "avg_flops_per_launch": flops}
-        if not args.no_cpu_baseline and args.layers is None:
+        if world == 1 and not args.no_cpu_baseline and args.layers is None:   # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(dims, res, args.num_timesteps)
         print(json.dumps(out))
     if world > 1:
