@@ -76,6 +76,11 @@ def exchange_velocities(local_v: Optional[torch.Tensor], ex: StepExchange, width
     if local_v is not None and local_v.shape[0] > 0:
         send[:local_v.shape[0]].copy_(local_v)
     recv = torch.empty((ex.world * ex.rows_max, width), device=device, dtype=dtype)
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo stages device tensors through the host on its own threads; with kernels still queued on the launch
+        # stream that hand-off was seen to hang (ROCm), so the rehearsal backend gets a drained stream.  RCCL
+        # ("nccl") orders the gather behind the stream's work itself.
+        torch.cuda.current_stream().synchronize()
     dist.all_gather_into_tensor(recv, send, group=group)
     if ex.index.device != recv.device:
         ex.index = ex.index.to(recv.device)   # once per image: the plan is reused by every step

@@ -40,6 +40,11 @@ def parse():
     ap.add_argument("--resolution", type=int, default=1024)
     ap.add_argument("--num-timesteps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="debug only: process-group backend (gloo lets several ranks "
+                                                      "rehearse on one GPU together with --share-gpu)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="debug only: at one GPU, open a one-rank RCCL group and run the per-step all-gather anyway")
+    ap.add_argument("--share-gpu", action="store_true", help="debug only: every rank uses cuda:0 (result is then INVALID)")
     ap.add_argument("--taylorseer", action="store_true",
                     help="enable_taylorseer=True (two of three forwards skipped after step 4): a different workload, "
                          "not the headline configuration")
@@ -89,15 +94,30 @@ def cpu_baseline(dims_full, resolution, num_timesteps):
 
 def main():
     args = parse()
+    if os.environ.get("BENCH_FAULT_TIMEOUT"):       # debug: dump every thread's stack if the run is still going then
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BENCH_FAULT_TIMEOUT"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world == 1 and args.force_gather:
+        import torch.distributed as dist
+        from bagel_amd import parallel
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        parallel.StepExchange.needs_gather = property(lambda self: True)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from bagel_amd.config import BAGEL_7B
     from bagel_amd.engine import MoTWeights
@@ -207,7 +227,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.layers is None:   # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(dims, res, args.num_timesteps)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_gather:
         import torch.distributed as dist
         dist.destroy_process_group()
 
