@@ -85,7 +85,8 @@ int bagel_qk_norm_rope_kv_bf16(const void* qkv, long ld, int M, int Hq, int Hkv,
  * Every query row of a tile attends key slots [kv_start, kv_start + kv_len) of its kv head; with
  * causal_base >= 0, row r of the tile only sees the first causal_base + r + 1 of them (the bottom-right
  * aligned causal mask of flash-attn >= 2.1; causal_base = context length + index of the tile's first row
- * among the sample's new tokens).  causal_base = -1 for the non-causal generation forward. */
+ * among the sample's new tokens).  causal_base = -1 for the non-causal generation forward.
+ * S (key slots per kv head, a multiple of 64) is limited to S * head_dim * 2 < 2^31 bytes. */
 int bagel_varlen_attention_bf16(const void* Q, const void* K_ws, const void* Vt_ws, void* O, const void* tiles,
                                 int n_tiles, int Hq, int Hkv, int head_dim, long S, void* stream);
 
