@@ -31,7 +31,8 @@ const char* bagel_last_error(void);
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T), bf16 operands, fp32 accumulation on the MFMA units.
  * Replaces the nn.Linear calls of the generation expert: q/k/v_proj_moe_gen (qwen2_navit.py:541-547),
  * o_proj_moe_gen (:605), mlp_moe_gen gate/up/down (:833, modeling_qwen2.py:200-201), vae2llm and
- * llm2vae (bagel.py:1396,1425), and the residual adds (:818,836).  K % 64 == 0, N % 4 == 0. */
+ * llm2vae (bagel.py:1396,1425), and the residual adds (:818,836).  K % 64 == 0, N % 4 == 0,
+ * lda and ldw (elements) multiples of 8 and below 2^21. */
 int bagel_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
                     const void* bias, const void* residual, long ldr, int epilogue, float alpha, void* stream);
 
