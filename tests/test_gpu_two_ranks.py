@@ -1,4 +1,4 @@
-"""The whole N > 1 generation path on real kernels: two processes share the box's one GPU (RCCL refuses two ranks
+"""The whole N > 1 generation path on real kernels: two or three processes share the box's one GPU (RCCL refuses two ranks
 on one device, so the group is gloo; the exchange itself is the same all_gather_into_tensor call), split the
 (sample, CFG-branch) units of every step, and must reproduce the single-process result bit for bit - CFG steps and
 cond-only steps, batch 2 with global renorm and an editing case with three different contexts."""
@@ -37,8 +37,11 @@ def _worker(rank, world, port, name, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["tiny_batch2", "tiny_edit3"])
-def test_two_ranks_reproduce_one(name):
+@pytest.mark.parametrize("name,world", [("tiny_batch2", 2), ("tiny_edit3", 2), ("tiny_t2i", 2), ("tiny_t2i", 3),
+                                        ("tiny_textcfg", 2)])
+def test_ranks_reproduce_one(name, world):
+    """tiny_t2i has cond-only steps (outside the CFG interval) in which all ranks but one own no unit at all;
+    tiny_edit3 splits one image's three branches 2 + 1; tiny_textcfg has two branches per sample."""
     from tests.gpu_common import run_scenario_on_gpu
     from tests.helpers import OracleRun
     from tests.scenarios import SCENARIOS
@@ -49,18 +52,18 @@ def test_two_ranks_reproduce_one(name):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
-    for _ in range(2):
+    for _ in range(world):
         rank, n_gathers, out = q.get(timeout=240)
         assert n_gathers == sc.num_timesteps - 1      # one exchange per Euler step
         got[rank] = out
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for r in range(2):          # x_t is replicated: both ranks hold every sample's final latent
+    for r in range(world):      # x_t is replicated: both ranks hold every sample's final latent
         assert len(got[r]) == len(base)
         for a, b in zip(got[r], base):
             assert torch.equal(a, b)
