@@ -6,6 +6,8 @@ torch is used only to own device memory and to name the current HIP stream.
 from __future__ import annotations
 
 import ctypes
+import glob
+import hashlib
 import os
 import re
 import subprocess
@@ -22,11 +24,27 @@ SOURCES = ["capi.hip", "gemm.hip", "skinny.hip", "attention.hip", "elementwise.h
 _lib: Optional[ctypes.CDLL] = None
 
 
+STAMP_PATH = LIB_PATH + ".sha256"   # travels with the library
+
+
+def source_digest() -> str:
+    """SHA-256 over every file the library is compiled from (csrc/*.hip, csrc/*.h, the public header)."""
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))) + [HEADER]:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/*.hip for gfx950 into bagel_amd/libbagel_hip.so (cross-compiles without a GPU)."""
+    """Compile csrc/*.hip for gfx950 into bagel_amd/libbagel_hip.so (cross-compiles without a GPU).
+
+    The library is rebuilt whenever the digest of its sources differs from the one recorded next to it at
+    the last build, so an edit to any kernel header is never silently ignored."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, "common.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    digest = source_digest()
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(STAMP_PATH) and open(STAMP_PATH).read().strip() == digest:
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
@@ -47,6 +65,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed: " + r.stdout.decode())
+    with open(STAMP_PATH, "w") as f:
+        f.write(digest + "\n")
     return LIB_PATH
 
 
@@ -63,6 +83,10 @@ def lib() -> ctypes.CDLL:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(the HIP extension is the only compute path; there is no fallback)")
+        stamp = open(STAMP_PATH).read().strip() if os.path.exists(STAMP_PATH) else None
+        if stamp != source_digest() and os.environ.get("BAGEL_ALLOW_STALE_LIB") != "1":
+            raise RuntimeError(f"{LIB_PATH} was not built from the sources in {CSRC} (digest mismatch): run "
+                               "`python -c 'import __graft_entry__ as g; g.build()'`")
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.bagel_last_error.restype = ctypes.c_char_p
         for name in ("bagel_skinny_gemm_workspace_bytes", "bagel_cfg_workspace_bytes", "bagel_groupnorm_workspace_bytes"):
@@ -83,11 +107,31 @@ def _p(t: Optional[torch.Tensor]):
     if t is None:
         return ctypes.c_void_p(0)
     assert t.is_cuda, "device tensor expected"
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: kernels are "
+                           "launched on the current device's stream (wrap the call in torch.cuda.device(...))")
     return ctypes.c_void_p(t.data_ptr())
 
 
 def _stream():
+    """The current HIP stream of the current device.  Every entry point launches on the current device, so
+    tensors must live there: _p() checks it."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def on_device(fn):
+    """Run a method with ``self.device`` as the current device: the kernels go to the current device's current
+    stream, so a model placed on cuda:1 must not be driven while cuda:0 is current."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        dev = getattr(self, "device", None)
+        if dev is None:
+            dev = (getattr(self, "engine", None) or self._engine).device
+        with torch.cuda.device(dev):
+            return fn(self, *args, **kwargs)
+    return wrapper
 
 
 L = ctypes.c_long

@@ -352,13 +352,7 @@ extern "C" int bagel_varlen_attention_scaled_bf16(const void* Q, const void* K, 
   p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.Vt = (const bf16*)Vt; p.O = (bf16*)O;
   p.tiles = (const AttnTile*)tiles; p.n_tiles = n_tiles; p.Hq = Hq; p.Hkv = Hkv; p.S = S;
   p.scale_log2 = 1.4426950408889634f * softmax_scale;
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
+  const int cus = bagel_cu_count();
   const bool deep = g_attn_deep >= 0 ? g_attn_deep != 0 : (long)n_tiles * Hq <= 2L * cus;
   const size_t tile_pair = (size_t)KT * head_dim * 2 * 2;  // one K tile + one Vt tile
   const size_t lds = deep ? 2 * tile_pair : tile_pair;

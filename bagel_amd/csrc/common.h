@@ -57,6 +57,20 @@ inline void bagel_allow_lds(BagelLdsAllowed& st, const void* kernel, int bytes) 
   if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess) st.devices |= bit;
 }
 
+// Compute units of the CURRENT device (256 on MI355X), cached per device ordinal.
+inline int bagel_cu_count() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int& slot = cached[dev & 63];
+  if (slot == 0) {
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+    slot = cu;
+  }
+  return slot;
+}
+
 #define BAGEL_LAUNCH_CHECK()                                               \
   do {                                                                     \
     hipError_t e_ = hipGetLastError();                                     \

@@ -31,14 +31,8 @@ static int g_gemm_persistent = 1;  // 0: one workgroup per output tile
 
 // CUs of the current device, rounded down to a multiple of the 8 XCDs (256 on MI355X)
 static int compute_units() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 8)
-      cu = 256;
-    n = cu / 8 * 8;
-  }
-  return n;
+  const int cu = bagel_cu_count();
+  return cu >= 8 ? cu / 8 * 8 : 256;
 }
 
 template <int BM, int BN, int WM, int WN>

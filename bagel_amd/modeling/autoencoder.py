@@ -127,6 +127,7 @@ class AutoEncoder:
                       bias=self.w[name + ".proj_out.bias"], residual=x, epilogue=K.EPI_BIAS_RESIDUAL)
 
     # ---- API --------------------------------------------------------------------------------------
+    @K.on_device
     @torch.no_grad()
     def decode(self, z: torch.Tensor) -> torch.Tensor:
         """z [1, z_channels, h, w] (fp32) -> image [1, 3, 8h, 8w] (bf16), AutoEncoder.decode (autoencoder.py:320-322)."""
@@ -169,6 +170,7 @@ class AutoEncoder:
         K.nhwc_to_nchw(o, npix, w_out.shape[0], v.out_ch, img)
         return img
 
+    @K.on_device
     @torch.no_grad()
     def encode_moments(self, x: torch.Tensor) -> torch.Tensor:
         """Encoder.forward (autoencoder.py:172-193) for one image: x [1, 3, H, W] -> NHWC moments
@@ -213,6 +215,7 @@ class AutoEncoder:
         out = torch.empty((npix, w_out.shape[0]), device=self.device, dtype=BF16)
         return K.conv3x3(t, H, W, C, w_out, self.w["encoder.conv_out.bias"], out, self.zero_page)
 
+    @K.on_device
     @torch.no_grad()
     def encode(self, x: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
         """AutoEncoder.encode (autoencoder.py:315-318): x [B, 3, H, W] -> z [B, z_channels, H/8, W/8] bf16.

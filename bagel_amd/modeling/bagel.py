@@ -132,6 +132,7 @@ class Bagel:
         }
         return generation_input, newlens, new_rope
 
+    @K.on_device
     @torch.no_grad()
     def forward_cache_update_text(self, past_key_values: NaiveCache, packed_text_ids, packed_text_position_ids,
                                   text_token_lens, packed_text_indexes, packed_key_value_indexes, key_values_lens):
@@ -243,6 +244,7 @@ class Bagel:
         })
         return gi, newlens, new_rope
 
+    @K.on_device
     @torch.no_grad()
     def forward_cache_update_vit(self, past_key_values: NaiveCache, packed_text_ids, packed_text_indexes,
                                  packed_vit_tokens, packed_vit_token_indexes, packed_vit_position_ids, vit_token_seqlens,
@@ -298,6 +300,7 @@ class Bagel:
         })
         return gi, newlens, new_rope
 
+    @K.on_device
     @torch.no_grad()
     def forward_cache_update_vae(self, vae_model, past_key_values: NaiveCache, padded_images, patchified_vae_latent_shapes,
                                  packed_vae_position_ids, packed_timesteps, packed_vae_token_indexes, packed_text_ids,
@@ -363,6 +366,7 @@ class Bagel:
             "packed_key_value_indexes": torch.tensor(packed_key_value_indexes, dtype=torch.long, device=device),
         }
 
+    @K.on_device
     @torch.no_grad()
     def generate_text(self, past_key_values: NaiveCache, packed_key_value_indexes, key_values_lens, packed_start_tokens,
                       packed_query_position_ids, max_length: int, do_sample: bool = False, temperature: float = 1.0,
@@ -509,6 +513,7 @@ class Bagel:
     # ------------------------------------------------------------------------------------------
     # sampler
     # ------------------------------------------------------------------------------------------
+    @K.on_device
     @torch.no_grad()
     def generate_image(
         self,
@@ -674,6 +679,7 @@ class Bagel:
 
         return x_t.split(sample_nv)
 
+    @K.on_device
     @torch.no_grad()
     def _forward_flow(self, x_t, timestep, packed_vae_token_indexes, packed_vae_position_ids, packed_text_ids,
                       packed_text_indexes, packed_indexes, packed_position_ids, packed_seqlens, key_values_lens,

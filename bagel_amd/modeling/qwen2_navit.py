@@ -31,6 +31,7 @@ class _EmbedTokens:
     def weight(self):
         return self._engine.w.embed_tokens
 
+    @K.on_device
     def __call__(self, ids: torch.Tensor) -> torch.Tensor:
         eng = self._engine
         flat = ids.reshape(-1).to(device=eng.device, dtype=torch.int32).contiguous()
@@ -48,6 +49,7 @@ class _LMHead:
     def weight(self):
         return self._engine.w.lm_head
 
+    @K.on_device
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         eng = self._engine
         if eng.w.lm_head is None:
@@ -76,6 +78,7 @@ class Qwen2ForCausalLM:
         self.model = _Qwen2Model(engine)
         self.lm_head = _LMHead(engine)
 
+    @K.on_device
     @torch.no_grad()
     def forward_inference(self, packed_query_sequence, query_lens, packed_query_position_ids, packed_query_indexes,
                           past_key_values=None, key_values_lens=None, packed_key_value_indexes=None,

@@ -78,6 +78,7 @@ class SiglipTower:
             self._buf[name] = cur
         return cur[:n].view(*shape)
 
+    @K.on_device
     @torch.no_grad()
     def tower(self, packed_pixel_values: torch.Tensor, position_ids: torch.Tensor, seqlens: Sequence[int]) -> torch.Tensor:
         """SiglipVisionModel.forward: [N, 3 p p] pixels -> [N, Hv] (post_layernorm output, bf16)."""
@@ -133,6 +134,7 @@ class SiglipTower:
         K.layernorm(X, Xn, self.post_w, self.post_b, eps)
         return Xn
 
+    @K.on_device
     @torch.no_grad()
     def embed(self, packed_vit_tokens, packed_vit_position_ids, vit_token_seqlens) -> torch.Tensor:
         """vit_model -> connector -> + vit_pos_embed (bagel.py:977-987): [N, H] bf16 rows for the LLM."""

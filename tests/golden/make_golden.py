@@ -38,11 +38,26 @@ def build_context(model, NaiveCache, prompts, n_samples, tok):
     """Prefill one CFG context the way InterleaveInferencer.update_context_text does (inferencer.py:57-76)."""
     past = NaiveCache(model.config.llm_config.num_hidden_layers)
     kvlens, ropes = [0] * n_samples, [0] * n_samples
+    gi = None
     if prompts is not None:
         gi, kvlens, ropes = model.prepare_prompts(kvlens, ropes, [" ".join(map(str, p)) for p in prompts],
                                                   tok, NEW_TOKEN_IDS)
+        gi = {k: v.clone() for k, v in gi.items()}
         past = model.forward_cache_update_text(past, **gi)
-    return past, kvlens, ropes
+    return past, kvlens, ropes, gi
+
+
+def save_index_tensors(out, tag, gi, extra=None):
+    """Record every integer tensor (and list of ints) a prepare_* call of the reference returned, under
+    ``idx.<tag>.<name>``: the product's host-side builders are compared with these bit for bit."""
+    for k, v in (gi or {}).items():
+        if isinstance(v, torch.Tensor):
+            if not v.dtype.is_floating_point:
+                out[f"idx.{tag}.{k}"] = v.detach().cpu().to(torch.int64).clone()
+        elif isinstance(v, (list, tuple)) and len(v) and all(isinstance(e, (list, tuple)) for e in v):
+            out[f"idx.{tag}.{k}"] = torch.tensor([list(e) for e in v], dtype=torch.int64)
+    for k, v in (extra or {}).items():
+        out[f"idx.{tag}.{k}"] = torch.tensor(list(v), dtype=torch.int64)
 
 
 def run_llm_scenario(sc):
@@ -60,6 +75,11 @@ def run_llm_scenario(sc):
         gt = model.prepare_vae_latent_cfg(ctx["text"][1], ctx["text"][2], sc.images)
         gm = model.prepare_vae_latent_cfg(ctx["img"][1], ctx["img"][2], sc.images)
         out["init_noise"] = gi["packed_init_noises"].clone()
+        for w in ("cond", "text", "img"):
+            save_index_tensors(out, f"prompts.{w}", ctx[w][3], {"newlens": ctx[w][1], "new_rope": ctx[w][2]})
+        save_index_tensors(out, "vae_latent", gi)
+        save_index_tensors(out, "vae_latent_cfg.text", gt)
+        save_index_tensors(out, "vae_latent_cfg.img", gm)
 
         steps = []
         branch_v = []
@@ -127,6 +147,7 @@ def run_llm_scenario(sc):
         vt, (c, x, m) = exact.step(i, rec["x_t"])
         for key, t in (("v_cond", c), ("v_text", x), ("v_img", m), ("v_t", vt)):
             if key in rec:
+                out[f"step{i}.exact.{key}"] = t.float().clone()
                 a, b = rec[key].float().flatten(), t.float().flatten()
                 d = (a - b).abs()
                 noise[f"step{i}.{key}"] = [float(d.max()), float(d.mean()),
@@ -151,7 +172,7 @@ def run_text_case(tc):
     logits = []
     hook = model.language_model.lm_head.register_forward_hook(lambda m, i, o: logits.append(o.clone()))
     with torch.no_grad(), rh.autocast():
-        past, kvlens, ropes = build_context(model, NaiveCache, tc.prompts(), len(tc.prompt), tok)
+        past, kvlens, ropes, pgi = build_context(model, NaiveCache, tc.prompts(), len(tc.prompt), tok)
         gi = model.prepare_start_tokens(kvlens, ropes, NEW_TOKEN_IDS)
         start = {k: v.clone() for k, v in gi.items()}   # generate_text edits packed_key_value_indexes in place
         tokens = model.generate_text(past_key_values=past, max_length=tc.max_length, do_sample=False, **gi)
@@ -159,6 +180,7 @@ def run_text_case(tc):
     out = {"tokens": tokens.to(torch.int64).contiguous(), "logits": torch.stack(logits).float().contiguous()}
     for k, v in start.items():
         out[f"start.{k}"] = v.to(torch.int64).contiguous()
+    save_index_tensors(out, "prompts", pgi, {"newlens": kvlens, "new_rope": ropes})
     save_file(out, os.path.join(HERE, f"{tc.name}.safetensors"),
               metadata={"source": "reference Bagel.generate_text (greedy) on CPU, bf16 weights + bf16 autocast, "
                                   "SDPA stand-in for flash_attn"})
@@ -197,9 +219,11 @@ def run_image_ctx_case(ic):
         if ic.first_prompt is not None:
             gi, kvlens, ropes = model.prepare_prompts(kvlens, ropes, [" ".join(map(str, p)) for p in ic.prompts("first")],
                                                       tok, NEW_TOKEN_IDS)
+            save_index_tensors(out, "prompts.first", gi, {"newlens": kvlens, "new_rope": ropes})
             past = model.forward_cache_update_text(past, **gi)
         if ic.vae_images is not None:
             gi, kvlens, ropes = model.prepare_vae_images(kvlens, ropes, ic.images("vae"), ident, NEW_TOKEN_IDS)
+            save_index_tensors(out, "vae_images", gi, {"newlens": kvlens, "new_rope": ropes})
             hooks = [vae.encoder.register_forward_hook(lambda m, i, o: out.__setitem__("vae.moments", o.float().clone()))]
             real_randn_like = torch.randn_like
 
@@ -220,6 +244,7 @@ def run_image_ctx_case(ic):
         ctx_before_vit = None
         if ic.vit_images is not None:
             gi, kvlens, ropes = model.prepare_vit_images(kvlens, ropes, ic.images("vit"), ident, NEW_TOKEN_IDS)
+            save_index_tensors(out, "vit_images", gi, {"newlens": kvlens, "new_rope": ropes})
             hooks = [model.vit_model.register_forward_hook(lambda m, i, o: out.__setitem__("vit.tower", o.float().clone())),
                      model.connector.register_forward_hook(lambda m, i, o: out.__setitem__("vit.connector", o.float().clone()))]
             past = model.forward_cache_update_vit(past, **gi)
@@ -242,6 +267,9 @@ def run_image_ctx_case(ic):
             g = model.prepare_vae_latent(kvlens, ropes, sizes, NEW_TOKEN_IDS)
             gt = model.prepare_vae_latent_cfg(text_ctx[1], text_ctx[2], sizes)
             gm = model.prepare_vae_latent_cfg(ikv, irope, sizes)
+            save_index_tensors(out, "edit.vae_latent", g)
+            save_index_tensors(out, "edit.vae_latent_cfg.text", gt)
+            save_index_tensors(out, "edit.vae_latent_cfg.img", gm)
             out["edit.init_noise"] = g["packed_init_noises"].clone()
             steps, branch_v = [], []
             vae_idx = g["packed_vae_token_indexes"]
@@ -279,7 +307,7 @@ def run_image_ctx_case(ic):
     print(f"[{ic.name}] wrote {len(out)} tensors in {time.time() - t0:.1f}s")
 
 
-VAE_CASES = {"vae_128": (16, 16), "vae_256": (32, 32), "vae_512x384": (64, 48)}
+VAE_CASES = {"vae_128": (16, 16), "vae_256": (32, 32), "vae_512x384": (64, 48), "vae_1024": (128, 128)}
 
 
 def run_vae(name, latent_hw):
@@ -293,9 +321,14 @@ def run_vae(name, latent_hw):
         img32 = ae.decode(z)
         with rh.autocast():
             img16 = ae.decode(z)
-    save_file({"z": z, "image_fp32": img32.float().contiguous(), "image_autocast": img16.float().contiguous()},
-              os.path.join(HERE, f"{name}.safetensors"),
-              metadata={"source": "reference AutoEncoder.decode on CPU, fp32 and under bf16 autocast"})
+    big = latent_hw[0] * latent_hw[1] > 64 * 64        # 1024 x 1024: images stored in fp16 (values in [-1.3, 1.3])
+    cast = (lambda t: t.half().contiguous()) if big else (lambda t: t.float().contiguous())
+    d = (img32.double() - img16.double())
+    meta = {"source": "reference AutoEncoder.decode on CPU, fp32 and under bf16 autocast",
+            "sum_fp32": repr(float(img32.double().sum())), "sum_autocast": repr(float(img16.double().sum())),
+            "psnr_autocast_vs_fp32": repr(float(10 * torch.log10(4.0 / (d * d).mean())))}
+    save_file({"z": z, "image_fp32": cast(img32), "image_autocast": cast(img16)},
+              os.path.join(HERE, f"{name}.safetensors"), metadata=meta)
     print(f"[{name}] wrote in {time.time() - t0:.1f}s; |fp32-autocast|max={float((img32 - img16.float()).abs().max()):.4f}")
 
 
