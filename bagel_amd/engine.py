@@ -289,15 +289,27 @@ class MoTEngine:
         return GenPlan(units, nv, Mv, Mt, S, kv_start, vae_row0, row_cs.to(dev), row_slot.to(dev), src_row.to(dev),
                        torch.tensor(tiles, dtype=torch.int32).to(dev), len(tiles), cos, sin)
 
+    @staticmethod
+    def _zero_value_padding(vtws: torch.Tensor, ranges):
+        """The attention kernel masks the scores of key slots past a sample's length, but their probabilities
+        (exact zeros) still multiply whatever the value slots hold, and 0 x NaN is NaN: the value slots between a
+        sample's last key and the end of its 64-slot padding must be finite.  Only those are cleared (a few
+        columns per sample), not the workspace (17 GB for a batch of long editing contexts).  Key slots need
+        nothing: masked scores are replaced, not multiplied."""
+        for a, b in ranges:
+            if b > a:
+                vtws[..., a:b].zero_()
+
     def load_context(self, plan: GenPlan):
         """Allocate the KV workspace and copy every unit's context keys/values into it (once per image).
-        K [L][Hkv][S][D] row-major, Vt [L][Hkv][D][S] transposed; zero-filled so padding slots are finite."""
+        K [L][Hkv][S][D] row-major, Vt [L][Hkv][D][S] transposed."""
         d = self.dims
         L, Hkv, D, S = d.num_layers, d.num_kv_heads, d.head_dim, plan.S
         self.kws = self._get("kws", (L, Hkv, S, D), zero=True)
         self.vtws = self._get("vtws", (L, Hkv, D, S), zero=True)
-        self.kws.zero_()
-        self.vtws.zero_()
+        ends = plan.kv_start[1:] + [S]
+        self._zero_value_padding(self.vtws, [(ks + u.ctx_len + n + 2, e) for u, n, ks, e in
+                                             zip(plan.units, plan.nv, plan.kv_start, ends)])
         for u, ks in zip(plan.units, plan.kv_start):
             if u.ctx_len == 0:
                 continue
@@ -431,8 +443,7 @@ class MoTEngine:
         L = d.num_layers
         kws = self._get("kws_und", (L, Hkv, S, D), zero=True)
         vtws = self._get("vtws_und", (L, Hkv, D, S), zero=True)
-        kws.zero_()
-        vtws.zero_()
+        self._zero_value_padding(vtws, [(ks + c + n, e) for ks, n, c, e in zip(kv_start, lens, ctx_lens, kv_start[1:] + [S])])
         positions, row_slot, tiles = [], [], []
         for b, (n, c) in enumerate(zip(lens, ctx_lens)):
             ks = kv_start[b]
@@ -516,8 +527,7 @@ class MoTEngine:
         S = s
         kws = self._get("kws_seq", (L, Hkv, S, D), zero=True)
         vtws = self._get("vtws_seq", (L, Hkv, D, S), zero=True)
-        kws.zero_()
-        vtws.zero_()
+        self._zero_value_padding(vtws, [(ks + c + n, e) for ks, n, c, e in zip(kv_start, lens, ctx_lens, kv_start[1:] + [S])])
         slot_of = [0] * M
         tiles = []
         for b, (n, c) in enumerate(zip(lens, ctx_lens)):
@@ -610,8 +620,8 @@ class MoTEngine:
         S = s
         kws = self._get("kws_dec", (L, Hkv, S, D), zero=True)
         vtws = self._get("vtws_dec", (L, Hkv, D, S), zero=True)
-        kws.zero_()
-        vtws.zero_()
+        # slots of tokens not generated yet are masked like padding until their step writes them
+        self._zero_value_padding(vtws, [(ks + c, e) for ks, c, e in zip(kv_start, ctx_lens, kv_start[1:] + [S])])
         for b, c in enumerate(ctx_lens):
             if c > 0:
                 for l in range(L):

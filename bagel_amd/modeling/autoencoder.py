@@ -58,6 +58,8 @@ class AutoEncoder:
                 self.w[name] = t.to(dev)                         # GroupNorm affine, fp32
         self.zero_page = torch.zeros(256, dtype=torch.uint8, device=dev)
         self._buf: Dict[str, torch.Tensor] = {}
+        # query rows of the mid-block attention whose fp32 scores are held at once (16384 keys x 4096 rows = 256 MiB)
+        self.score_chunk = 4096
 
     def eval(self):
         return self
@@ -113,7 +115,7 @@ class AutoEncoder:
         vt = K.transpose(vbuf, self._get("avt", (C, npad)))
         o = self._get("ao", (n, C))
         # scores in row chunks so the fp32 score matrix stays bounded (n can be 16384)
-        chunk = min(n, 4096)
+        chunk = min(n, self.score_chunk)
         s = self._get("as", (chunk, npad), torch.float32)
         p = self._get("ap", (chunk, npad))
         if npad != n:

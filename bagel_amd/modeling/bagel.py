@@ -12,6 +12,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from .. import _lib as K
+from .. import packing
 from ..config import BagelDims
 from ..engine import GenUnit, MoTEngine, MoTWeights, TaylorSchedule, TaylorStep
 from ..parallel import exchange_velocities, plan_exchange, world_info
@@ -38,10 +39,7 @@ class NaiveCache:
         return 0
 
 
-def get_flattened_position_ids_extrapolate(img_h, img_w, patch_size, max_num_patches_per_side):
-    """data/data_utils.py:53-58."""
-    nh, nw = img_h // patch_size, img_w // patch_size
-    return (torch.arange(0, nh)[:, None] * max_num_patches_per_side + torch.arange(0, nw)).flatten()
+get_flattened_position_ids_extrapolate = packing.flattened_position_ids_extrapolate
 
 
 class _LLMConfig:
@@ -101,36 +99,11 @@ class Bagel:
         return self
 
     # ------------------------------------------------------------------------------------------
-    # host index builders (bit-for-bit the reference's lists, incl. the CPU RNG draw order)
+    # host index builders: thin delegates, the index work lives in bagel_amd/packing.py
     # ------------------------------------------------------------------------------------------
     def prepare_prompts(self, curr_kvlens, curr_rope, prompts, tokenizer, new_token_ids):
-        """bagel.py:806-841."""
-        packed_text_ids, packed_text_position_ids, text_token_lens = [], [], []
-        packed_text_indexes, packed_key_value_indexes = [], []
-        curr = 0
-        newlens, new_rope = [], []
-        for prompt, curr_kvlen, curr_position_id in zip(prompts, curr_kvlens, curr_rope):
-            packed_key_value_indexes.extend(range(curr, curr + curr_kvlen))
-            curr += curr_kvlen
-            text_ids = tokenizer.encode(prompt)
-            text_ids = [new_token_ids["bos_token_id"]] + text_ids + [new_token_ids["eos_token_id"]]
-            text_token_lens.append(len(text_ids))
-            packed_text_ids.extend(text_ids)
-            packed_text_position_ids.extend(range(curr_position_id, curr_position_id + len(text_ids)))
-            packed_text_indexes.extend(range(curr, curr + len(text_ids)))
-            newlens.append(curr_kvlen + len(text_ids))
-            new_rope.append(curr_position_id + len(text_ids))
-            curr += len(text_ids)
-        device = self.device
-        generation_input = {
-            "text_token_lens": torch.tensor(text_token_lens, dtype=torch.int, device=device),
-            "packed_text_ids": torch.tensor(packed_text_ids, dtype=torch.long, device=device),
-            "packed_text_position_ids": torch.tensor(packed_text_position_ids, dtype=torch.long, device=device),
-            "packed_text_indexes": torch.tensor(packed_text_indexes, dtype=torch.long, device=device),
-            "packed_key_value_indexes": torch.tensor(packed_key_value_indexes, dtype=torch.long, device=device),
-            "key_values_lens": torch.tensor(curr_kvlens, dtype=torch.int, device=device),
-        }
-        return generation_input, newlens, new_rope
+        """bagel.py:806-841 (index work in bagel_amd/packing.py)."""
+        return packing.prepare_prompts(curr_kvlens, curr_rope, prompts, tokenizer, new_token_ids, device=self.device)
 
     @K.on_device
     @torch.no_grad()
@@ -173,44 +146,6 @@ class Bagel:
     # ------------------------------------------------------------------------------------------
     # image inputs: ViT tokens (understanding) and VAE tokens (generation expert) into the context
     # ------------------------------------------------------------------------------------------
-    def _prepare_image_tokens(self, curr_kvlens, curr_rope, token_counts, new_token_ids):
-        """Index lists shared by prepare_vit_images and prepare_vae_images (bagel.py:883-920, 1017-1058):
-        per sample [start_of_image, image tokens, end_of_image], all at the sample's current RoPE position."""
-        img_idx, text_ids, text_idx, seqlens, pos_ids, idx, kvidx = [], [], [], [], [], [], []
-        _curr = curr = 0
-        newlens, new_rope = [], []
-        for n, kvlen, rope in zip(token_counts, curr_kvlens, curr_rope):
-            kvidx.extend(range(curr, curr + kvlen))
-            curr += kvlen
-            text_ids.append(new_token_ids["start_of_image"])
-            text_idx.append(_curr)
-            idx.append(curr)
-            curr += 1
-            _curr += 1
-            img_idx.extend(range(_curr, _curr + n))
-            idx.extend(range(curr, curr + n))
-            curr += n
-            _curr += n
-            text_ids.append(new_token_ids["end_of_image"])
-            text_idx.append(_curr)
-            idx.append(curr)
-            curr += 1
-            _curr += 1
-            pos_ids.extend([rope] * (n + 2))
-            seqlens.append(n + 2)
-            newlens.append(kvlen + n + 2)
-            new_rope.append(rope + 1)
-        gi = {
-            "packed_text_ids": torch.tensor(text_ids, dtype=torch.long),
-            "packed_text_indexes": torch.tensor(text_idx, dtype=torch.long),
-            "packed_position_ids": torch.tensor(pos_ids, dtype=torch.long),
-            "packed_seqlens": torch.tensor(seqlens, dtype=torch.int),
-            "packed_indexes": torch.tensor(idx, dtype=torch.long),
-            "packed_key_value_indexes": torch.tensor(kvidx, dtype=torch.long),
-            "key_values_lens": torch.tensor(curr_kvlens, dtype=torch.int),
-        }
-        return gi, img_idx, newlens, new_rope
-
     def _image_context(self, past_key_values, packed_seqlens, packed_position_ids, packed_indexes, key_values_lens,
                        packed_key_value_indexes, packed_text_indexes, image_token_indexes):
         """Validate the [soi, image tokens, eoi] per-sample layout and slice the context per sample."""
@@ -225,24 +160,8 @@ class Bagel:
         if self.dims.vit is None:
             raise ValueError("this model was built without a vision tower (dims.vit is None)")
         vit = self.dims.vit
-        toks, pos = [], []
-        for image in images:
-            t = transforms(image)
-            pos.append(self.get_flattened_position_ids(t.size(1), t.size(2), vit.patch_size,
-                                                       max_num_patches_per_side=vit.max_patches_per_side))
-            c, h, w = t.shape
-            assert h % vit.patch_size == 0 and w % vit.patch_size == 0
-            q = vit.patch_size
-            toks.append(torch.einsum("chpwq->hwpqc", t.reshape(c, h // q, q, w // q, q)).reshape(-1, q * q * c))
-        gi, img_idx, newlens, new_rope = self._prepare_image_tokens(curr_kvlens, curr_rope, [t.shape[0] for t in toks],
-                                                                    new_token_ids)
-        gi.update({
-            "vit_token_seqlens": torch.tensor([t.shape[0] for t in toks], dtype=torch.int),
-            "packed_vit_tokens": torch.cat(toks, dim=0),
-            "packed_vit_position_ids": torch.cat(pos, dim=0),
-            "packed_vit_token_indexes": torch.tensor(img_idx, dtype=torch.long),
-        })
-        return gi, newlens, new_rope
+        return packing.prepare_vit_images(curr_kvlens, curr_rope, images, transforms, new_token_ids, vit.patch_size,
+                                          vit.max_patches_per_side)
 
     @K.on_device
     @torch.no_grad()
@@ -280,25 +199,8 @@ class Bagel:
 
     def prepare_vae_images(self, curr_kvlens, curr_rope, images, transforms, new_token_ids, timestep=0):
         """bagel.py:1010-1081."""
-        ds = self.latent_downsample
-        tensors = [transforms(image) for image in images]
-        shapes = [(t.shape[1] // ds, t.shape[2] // ds) for t in tensors]
-        pos = [self.get_flattened_position_ids(t.size(1), t.size(2), ds, max_num_patches_per_side=self.max_latent_size)
-               for t in tensors]
-        gi, img_idx, newlens, new_rope = self._prepare_image_tokens(curr_kvlens, curr_rope, [h * w for h, w in shapes],
-                                                                    new_token_ids)
-        size = [max(s) for s in zip(*[t.shape for t in tensors])]
-        padded = torch.zeros(size=(len(tensors), *size))
-        for i, t in enumerate(tensors):
-            padded[i, :, :t.shape[1], :t.shape[2]] = t
-        gi.update({
-            "padded_images": padded,
-            "patchified_vae_latent_shapes": shapes,
-            "packed_vae_position_ids": torch.cat(pos, dim=0),
-            "packed_timesteps": torch.tensor([timestep]),
-            "packed_vae_token_indexes": torch.tensor(img_idx, dtype=torch.long),
-        })
-        return gi, newlens, new_rope
+        return packing.prepare_vae_images(curr_kvlens, curr_rope, images, transforms, new_token_ids,
+                                          self.latent_downsample, self.max_latent_size, timestep=timestep)
 
     @K.on_device
     @torch.no_grad()
@@ -351,20 +253,7 @@ class Bagel:
 
     def prepare_start_tokens(self, curr_kvlens, curr_rope, new_token_ids):
         """bagel.py:1502-1523."""
-        packed_start_tokens, packed_key_value_indexes, packed_query_position_ids = [], [], []
-        curr = 0
-        for curr_kvlen, curr_position_id in zip(curr_kvlens, curr_rope):
-            packed_key_value_indexes.extend(range(curr, curr + curr_kvlen))
-            packed_start_tokens.append(new_token_ids["bos_token_id"])
-            packed_query_position_ids.append(curr_position_id)
-            curr += curr_kvlen
-        device = self.device
-        return {
-            "packed_start_tokens": torch.tensor(packed_start_tokens, dtype=torch.long, device=device),
-            "packed_query_position_ids": torch.tensor(packed_query_position_ids, dtype=torch.long, device=device),
-            "key_values_lens": torch.tensor(curr_kvlens, dtype=torch.int, device=device),
-            "packed_key_value_indexes": torch.tensor(packed_key_value_indexes, dtype=torch.long, device=device),
-        }
+        return packing.prepare_start_tokens(curr_kvlens, curr_rope, new_token_ids, device=self.device)
 
     @K.on_device
     @torch.no_grad()
@@ -402,65 +291,12 @@ class Bagel:
 
     def prepare_vae_latent(self, curr_kvlens, curr_rope, image_sizes, new_token_ids):
         """bagel.py:1145-1201."""
-        packed_text_ids, packed_text_indexes = [], []
-        packed_vae_position_ids, packed_vae_token_indexes, packed_init_noises = [], [], []
-        packed_position_ids, packed_seqlens, packed_indexes = [], [], []
-        packed_key_value_indexes = []
-        query_curr = curr = 0
-        for (H, W), curr_kvlen, curr_position_id in zip(image_sizes, curr_kvlens, curr_rope):
-            packed_key_value_indexes.extend(range(curr, curr + curr_kvlen))
-            curr += curr_kvlen
-            packed_text_ids.append(new_token_ids["start_of_image"])
-            packed_text_indexes.append(query_curr)
-            packed_indexes.append(curr)
-            curr += 1
-            query_curr += 1
-            packed_vae_position_ids.append(self.get_flattened_position_ids(
-                H, W, self.latent_downsample, max_num_patches_per_side=self.max_latent_size))
-            h, w = H // self.latent_downsample, W // self.latent_downsample
-            num_image_tokens = h * w
-            packed_init_noises.append(torch.randn(num_image_tokens, self.latent_channel * self.latent_patch_size ** 2))
-            packed_vae_token_indexes.extend(range(query_curr, query_curr + num_image_tokens))
-            packed_indexes.extend(range(curr, curr + num_image_tokens))
-            curr += num_image_tokens
-            query_curr += num_image_tokens
-            packed_text_ids.append(new_token_ids["end_of_image"])
-            packed_text_indexes.append(query_curr)
-            packed_indexes.append(curr)
-            curr += 1
-            query_curr += 1
-            packed_position_ids.extend([curr_position_id] * (num_image_tokens + 2))
-            packed_seqlens.append(num_image_tokens + 2)
-        return {
-            "packed_text_ids": torch.tensor(packed_text_ids, dtype=torch.long),
-            "packed_text_indexes": torch.tensor(packed_text_indexes, dtype=torch.long),
-            "packed_init_noises": torch.cat(packed_init_noises, dim=0),
-            "packed_vae_position_ids": torch.cat(packed_vae_position_ids, dim=0),
-            "packed_vae_token_indexes": torch.tensor(packed_vae_token_indexes, dtype=torch.long),
-            "packed_seqlens": torch.tensor(packed_seqlens, dtype=torch.int),
-            "packed_position_ids": torch.tensor(packed_position_ids, dtype=torch.long),
-            "key_values_lens": torch.tensor(curr_kvlens, dtype=torch.int),
-            "packed_indexes": torch.tensor(packed_indexes, dtype=torch.long),
-            "packed_key_value_indexes": torch.tensor(packed_key_value_indexes, dtype=torch.long),
-        }
+        return packing.prepare_vae_latent(curr_kvlens, curr_rope, image_sizes, new_token_ids, self.latent_downsample,
+                                          self.max_latent_size, self.patch_latent_dim)
 
     def prepare_vae_latent_cfg(self, curr_kvlens, curr_rope, image_sizes):
         """bagel.py:1203-1234."""
-        packed_position_ids, packed_indexes, packed_key_value_indexes = [], [], []
-        curr = 0
-        for (H, W), curr_kvlen, curr_position_id in zip(image_sizes, curr_kvlens, curr_rope):
-            packed_key_value_indexes.extend(range(curr, curr + curr_kvlen))
-            curr += curr_kvlen
-            n = (H // self.latent_downsample) * (W // self.latent_downsample)
-            packed_indexes.extend(range(curr, curr + n + 2))
-            curr += n + 2
-            packed_position_ids.extend([curr_position_id] * (n + 2))
-        return {
-            "cfg_packed_position_ids": torch.tensor(packed_position_ids, dtype=torch.long),
-            "cfg_key_values_lens": torch.tensor(curr_kvlens, dtype=torch.int),
-            "cfg_packed_query_indexes": torch.tensor(packed_indexes, dtype=torch.long),
-            "cfg_packed_key_value_indexes": torch.tensor(packed_key_value_indexes, dtype=torch.long),
-        }
+        return packing.prepare_vae_latent_cfg(curr_kvlens, curr_rope, image_sizes, self.latent_downsample)
 
     # ------------------------------------------------------------------------------------------
     # translation of the packed-index API into engine units

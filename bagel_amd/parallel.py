@@ -39,6 +39,8 @@ class StepExchange:
     rows_max: int                 # padded per-rank row count of the gather buffer
     index: torch.Tensor           # [n_branches_active * Nv] row of the gathered buffer for every global row
     world: int
+    send: Optional[torch.Tensor] = None   # [rows_max, width] and [world * rows_max, width]: allocated at the first
+    recv: Optional[torch.Tensor] = None   # step of an image and reused by every later step of this kind
 
     @property
     def needs_gather(self) -> bool:
@@ -72,16 +74,17 @@ def exchange_velocities(local_v: Optional[torch.Tensor], ex: StepExchange, width
     """
     if not ex.needs_gather:
         return local_v
-    send = torch.zeros((ex.rows_max, width), device=device, dtype=dtype)
+    if ex.send is None or ex.send.shape[1] != width or ex.send.dtype != dtype or ex.send.device != torch.device(device):
+        ex.send = torch.zeros((ex.rows_max, width), device=device, dtype=dtype)     # pad rows stay zero
+        ex.recv = torch.empty((ex.world * ex.rows_max, width), device=device, dtype=dtype)
+        ex.index = ex.index.to(device)
+    send, recv = ex.send, ex.recv
     if local_v is not None and local_v.shape[0] > 0:
         send[:local_v.shape[0]].copy_(local_v)
-    recv = torch.empty((ex.world * ex.rows_max, width), device=device, dtype=dtype)
     if send.is_cuda and dist.get_backend(group) == "gloo":
         # gloo stages device tensors through the host on its own threads; with kernels still queued on the launch
         # stream that hand-off was seen to hang (ROCm), so the rehearsal backend gets a drained stream.  RCCL
         # ("nccl") orders the gather behind the stream's work itself.
         torch.cuda.current_stream().synchronize()
     dist.all_gather_into_tensor(recv, send, group=group)
-    if ex.index.device != recv.device:
-        ex.index = ex.index.to(recv.device)   # once per image: the plan is reused by every step
     return recv.index_select(0, ex.index)

@@ -190,8 +190,14 @@ def main():
     elapsed = time.perf_counter() - t0
     events = model.engine.profile_events
     model.engine.profile_events = None
+    ranks_info = {"world_size_seen": 1, "backend": None, "per_rank_ms_per_step": [elapsed / args.steps * 1e3],
+                  "devices": [torch.cuda.get_device_name(dev)]}
     if world > 1:
         import torch.distributed as dist
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, (elapsed / args.steps * 1e3, torch.cuda.get_device_name(dev), local_rank))
+        ranks_info = {"world_size_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                      "per_rank_ms_per_step": [p[0] for p in per_rank], "devices": [f"{p[1]} (local rank {p[2]})" for p in per_rank]}
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -208,7 +214,7 @@ def main():
                                    f"num_timesteps={args.num_timesteps}, cfg_text 4.0 + cfg_img 1.5, "
                                    f"cfg_interval (0.4,1.0), global renorm, random-init weights, 34-token context; "
                                    f"one step = one generate_image call for the batch + VAE decode to uint8 of every image",
-                       "taylorseer": bool(args.taylorseer), "global_batch": B, "units_per_rank_per_cfg_step": 3, "parallelism": f"cfg-branch x batch over {world} GPU"},
+                       "ranks": ranks_info, "taylorseer": bool(args.taylorseer), "global_batch": B, "units_per_rank_per_cfg_step": 3, "parallelism": f"cfg-branch x batch over {world} GPU"},
         }
         if events:
             ms = [a.elapsed_time(b) for a, b, _ in events]

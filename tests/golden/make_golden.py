@@ -53,7 +53,7 @@ def save_index_tensors(out, tag, gi, extra=None):
     for k, v in (gi or {}).items():
         if isinstance(v, torch.Tensor):
             if not v.dtype.is_floating_point:
-                out[f"idx.{tag}.{k}"] = v.detach().cpu().to(torch.int64).clone()
+                out[f"idx.{tag}.{k}"] = v.detach().cpu().clone()          # dtype kept: int32 lens, int64 indexes
         elif isinstance(v, (list, tuple)) and len(v) and all(isinstance(e, (list, tuple)) for e in v):
             out[f"idx.{tag}.{k}"] = torch.tensor([list(e) for e in v], dtype=torch.int64)
     for k, v in (extra or {}).items():

@@ -10,7 +10,9 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
 
-from bagel_amd.config import BagelDims, tiny_dims, width7b_dims, BAGEL_0P5B
+import dataclasses
+
+from bagel_amd.config import BagelDims, ViTDims, tiny_dims, width7b_dims, BAGEL_0P5B
 
 NEW_TOKEN_IDS = dict(bos_token_id=1, eos_token_id=2, start_of_image=3, end_of_image=4)
 
@@ -149,4 +151,8 @@ IMAGE_CTX_CASES = {c.name: c for c in [
     ImageCtxCase("ctx_vae_tiny", tiny_dims(2, vit=True), None, [(64, 96), (128, 64)], None),
     ImageCtxCase("edit_tiny", tiny_dims(3, vit=True), None, [(128, 96)], [(112, 84)], edit_prompt=[11],
                  out_image=(128, 96)),
+    # the SigLIP so400m tower at its true width (1152 hidden, 16 heads of 72, MLP 4304, 70 x 70 position grid) and
+    # reduced depth, two images of different size packed (20 x 28 and 31 x 12 patches), tiny language model behind it
+    ImageCtxCase("ctx_vit_so400m", dataclasses.replace(tiny_dims(2), vit=ViTDims(num_layers=3)), [4, 6], None,
+                 [(280, 392), (434, 168)]),
 ]}

@@ -1,0 +1,232 @@
+"""Size-independent properties of the other workloads at their full size (BAGEL-7B dims, 28 layers, SigLIP so400m
+tower with 26 layers, FLUX VAE) - shapes no CPU checker finishes in seconds, so they are pinned by determinism,
+packing / batch invariance and finiteness rather than by golden vectors:
+
+  * image editing: batch 8, three CFG branches with contexts of 9034 / 9000 / 34 tokens (24 units, 98 k rows in
+    one packed forward), text_channel renorm (app.py:224-228, eval/gen/gen_images_mp_imgedit.py:278-407);
+  * context building from mixed-resolution images: VAE encode + VAE-token prefill, SigLIP tower + connector +
+    ViT-token prefill, prompt prefill (bagel.py:876-1143, siglip_navit.py:198-371);
+  * think-then-generate: 300 greedily decoded tokens over a 400-token context, pushed back into the context, then
+    a 1024 x 1024 generation over it (bagel.py:1526-1596, inferencer.py:273-305).
+
+Random-init weights generated on the device.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF16 = torch.bfloat16
+IDS = dict(bos_token_id=1, eos_token_id=2, start_of_image=3, end_of_image=4)
+
+
+class _Tok:
+    def encode(self, s):
+        return [int(t) for t in s.split()]
+
+
+@pytest.fixture(scope="module")
+def full():
+    from bagel_amd.config import BAGEL_7B, VAEDims
+    from bagel_amd.engine import MoTWeights
+    from bagel_amd.modeling import AutoEncoder, Bagel
+    from bagel_amd.weights import make_vae_encoder_state_dict, make_vit_state_dict
+    dims = BAGEL_7B
+    dev = torch.device(DEV)
+    weights = MoTWeights.random(dims, dev, seed=0, vocab_rows=1024)
+    model = Bagel(dims, state_dict=make_vit_state_dict(dims, seed=0), device=dev, weights=weights)
+    vae = AutoEncoder(VAEDims(), make_vae_encoder_state_dict(VAEDims(), seed=0), dev)
+    yield model, vae, dims
+    del model, vae
+    torch.cuda.empty_cache()
+
+
+def _tile_cache(cache, times, dims):
+    from bagel_amd.modeling import NaiveCache
+    out = NaiveCache(dims.num_layers)
+    for l in range(dims.num_layers):
+        out.key_cache[l] = cache.key_cache[l].repeat(times, 1, 1)
+        out.value_cache[l] = cache.value_cache[l].repeat(times, 1, 1)
+    return out
+
+
+def _edit_step(model, caches, lens, x, B, trace):
+    res = (1024, 1024)
+    c_cond, c_text, c_img = lens
+    torch.manual_seed(0)
+    gi = model.prepare_vae_latent([c_cond] * B, [3] * B, [res] * B, IDS)
+    gt = model.prepare_vae_latent_cfg([c_text] * B, [2] * B, [res] * B)
+    gm = model.prepare_vae_latent_cfg([c_img] * B, [c_img] * B, [res] * B)
+    gi["packed_init_noises"] = x
+    return model.generate_image(
+        past_key_values=caches[0], num_timesteps=50, timestep_shift=3.0, cfg_renorm_min=0.0,
+        cfg_renorm_type="text_channel", cfg_interval=[0.0, 1.0], cfg_text_scale=4.0, cfg_text_past_key_values=caches[1],
+        cfg_text_packed_position_ids=gt["cfg_packed_position_ids"],
+        cfg_text_packed_query_indexes=gt["cfg_packed_query_indexes"], cfg_text_key_values_lens=gt["cfg_key_values_lens"],
+        cfg_text_packed_key_value_indexes=gt["cfg_packed_key_value_indexes"], cfg_img_scale=2.0,
+        cfg_img_past_key_values=caches[2], cfg_img_packed_position_ids=gm["cfg_packed_position_ids"],
+        cfg_img_packed_query_indexes=gm["cfg_packed_query_indexes"], cfg_img_key_values_lens=gm["cfg_key_values_lens"],
+        cfg_img_packed_key_value_indexes=gm["cfg_packed_key_value_indexes"], max_steps=1, trace=trace, **gi)
+
+
+def test_edit_batch8_three_long_contexts(full):
+    """24 units in one packed forward.  Eight copies of one sample (same contexts, same noise) must each reproduce
+    the single-sample result bit for bit (samples only meet in the packed GEMM rows and the tile tables; the
+    text_channel renorm is per token), twice in a row (determinism)."""
+    from bench import synthetic_context
+    model, _, dims = full
+    dev = torch.device(DEV)
+    lens = (9034, 9000, 34)
+    one = [synthetic_context(dims, 1, c, dev, s) for c, s in zip(lens, (1, 2, 3))]
+    Nv, P = 4096, dims.patch_latent_dim
+    x1 = torch.randn((Nv, P), generator=torch.Generator().manual_seed(8))
+    t1 = []
+    lat1 = _edit_step(model, one, lens, x1, 1, t1)
+    B = 8
+    many = [_tile_cache(c, B, dims) for c in one]
+    t8, t8b = [], []
+    lat8 = _edit_step(model, many, lens, x1.repeat(B, 1), B, t8)
+    _edit_step(model, many, lens, x1.repeat(B, 1), B, t8b)
+    assert len(lat8) == B and len(t8) == 1
+    for k in ("v_cond", "v_text", "v_img", "v_t"):
+        v8 = t8[0][k]
+        assert v8.shape == (B * Nv, P) and torch.isfinite(v8.float()).all(), k
+        assert torch.equal(v8, t8b[0][k]), f"{k}: two identical calls differ"
+        for b in range(B):
+            assert torch.equal(v8[b * Nv:(b + 1) * Nv], t1[0][k]), f"{k}: sample {b} of the batch differs from the single-sample run"
+    for b in range(B):
+        assert torch.equal(lat8[b], lat1[0])
+    assert 0.05 < float(t1[0]["v_cond"].float().std()) < 50
+
+
+def test_mixed_resolution_context_building(full):
+    """Three images of different size through both image paths, then prompts."""
+    from bagel_amd.modeling import NaiveCache
+    model, vae, dims = full
+    L = dims.num_layers
+    g = torch.Generator().manual_seed(0)
+    vae_sizes = ((512, 768), (1024, 1024), (768, 576))
+    vit_sizes = ((490, 742), (980, 980), (742, 560))
+    vae_imgs = [torch.rand((3, h, w), generator=g) * 2 - 1 for h, w in vae_sizes]
+    vit_imgs = [torch.rand((3, h, w), generator=g) * 2 - 1 for h, w in vit_sizes]
+    ident = lambda x: x  # noqa: E731
+    B = 3
+    noise = torch.randn((B, 16, 128, 128), generator=g).to(BF16)      # posterior draw of the padded batch
+
+    def build(vimgs, timgs, nz, prompt_len=32):
+        n = len(vimgs)
+        past = NaiveCache(L)
+        kv, rope = [0] * n, [0] * n
+        gi, kv, rope = model.prepare_vae_images(kv, rope, vimgs, ident, IDS)
+        past = model.forward_cache_update_vae(vae, past, latent_noise=nz, **gi)
+        after_vae = (list(kv), [past.key_cache[l].clone() for l in (0, L - 1)], [past.value_cache[l].clone() for l in (0, L - 1)])
+        gi, kv, rope = model.prepare_vit_images(kv, rope, timgs, ident, IDS)
+        past = model.forward_cache_update_vit(past, **gi)
+        gi, kv, rope = model.prepare_prompts(kv, rope, [" ".join(str(10 + i) for i in range(prompt_len))] * n, _Tok(), IDS)
+        past = model.forward_cache_update_text(past, **gi)
+        return kv, rope, past, after_vae
+
+    kv, rope, past, after_vae = build(vae_imgs, vit_imgs, noise)
+    want = [(h // 16) * (w // 16) + 2 + (hh // 14) * (ww // 14) + 2 + 34 for (h, w), (hh, ww) in zip(vae_sizes, vit_sizes)]
+    assert kv == want and rope == [2 + 34] * B
+    for l in (0, L - 1):
+        assert past.key_cache[l].shape == (sum(kv), dims.num_kv_heads, dims.head_dim)
+        assert torch.isfinite(past.key_cache[l].float()).all() and torch.isfinite(past.value_cache[l].float()).all()
+        assert 0.05 < float(past.key_cache[l].float().std()) < 50
+    # determinism
+    kv2, _, past2, _ = build(vae_imgs, vit_imgs, noise)
+    for l in (0, L - 1):
+        assert torch.equal(past.key_cache[l], past2.key_cache[l]) and torch.equal(past.value_cache[l], past2.value_cache[l])
+    # packing invariance: the 1024 x 1024 image needs no padding, so alone it must give exactly the keys/values it
+    # gives inside the batch (both image paths and the prompt; the smaller images are encoded zero-padded to the
+    # batch's largest size, as the reference does, so they legitimately differ from their stand-alone encodes)
+    # The prompt rows are the exception: 34 rows alone take the weight-streaming GEMM (split-K partial sums), 3 x 34
+    # packed rows the MFMA tile GEMM, so their keys agree to rounding, not bit for bit.
+    kv1, _, past1, after_vae1 = build(vae_imgs[1:2], vit_imgs[1:2], noise[1:2])
+    assert kv1 == [kv[1]]
+    off, n_img = kv[0], kv[1] - 34
+    for l in (0, L - 1):
+        for got, ref in ((past1.key_cache[l], past.key_cache[l][off:off + kv[1]]),
+                         (past1.value_cache[l], past.value_cache[l][off:off + kv[1]])):
+            assert torch.equal(got[:n_img], ref[:n_img]), l
+            a, b = got[n_img:].float().flatten(), ref[n_img:].float().flatten()
+            assert float(torch.dot(a, b) / (a.norm() * b.norm())) >= 0.9999, l
+    off_v = after_vae[0][0]
+    for i in range(2):
+        assert torch.equal(after_vae1[1][i], after_vae[1][i][off_v:off_v + after_vae[0][1]])
+
+
+def test_vit_tower_so400m_packing_invariance(full):
+    """The vision tower alone at its full size (26 layers, 16 heads of 72 zero-padded to 128): an image's tokens do
+    not depend on what else is packed with it, and two runs agree bit for bit."""
+    model, _, dims = full
+    g = torch.Generator().manual_seed(1)
+    imgs = [torch.rand((3, h, w), generator=g) * 2 - 1 for h, w in ((490, 742), (980, 980), (154, 70))]
+    ident = lambda x: x  # noqa: E731
+    gi, _, _ = model.prepare_vit_images([0] * 3, [0] * 3, imgs, ident, IDS)
+    lens = gi["vit_token_seqlens"].tolist()
+    assert lens == [35 * 53, 70 * 70, 11 * 5]
+    a = model.vit_tower.tower(gi["packed_vit_tokens"], gi["packed_vit_position_ids"], lens).clone()
+    b = model.vit_tower.tower(gi["packed_vit_tokens"], gi["packed_vit_position_ids"], lens)
+    assert a.shape == (sum(lens), dims.vit.hidden_size) and torch.isfinite(a.float()).all() and torch.equal(a, b)
+    r = 0
+    for i, n in enumerate(lens):
+        gi1, _, _ = model.prepare_vit_images([0], [0], imgs[i:i + 1], ident, IDS)
+        alone = model.vit_tower.tower(gi1["packed_vit_tokens"], gi1["packed_vit_position_ids"], [n])
+        assert torch.equal(alone, a[r:r + n]), f"image {i} ({n} tokens) depends on its batch"
+        r += n
+
+
+def test_think_then_generate(full):
+    """300 greedy tokens over a 400-token context (twice: identical; a shorter run is a prefix of the longer one),
+    the text pushed back into the context, then two flow steps of a 1024 x 1024 generation over it."""
+    from bench import synthetic_context
+    model, _, dims = full
+    dev = torch.device(DEV)
+    w = model.engine.w
+    if w.lm_head is None or w.lm_head.shape[0] != 4096:
+        # a 4096-row slice of the vocabulary keeps the test's memory modest; the GEMV path is the same
+        gen = torch.Generator(device=dev).manual_seed(5)
+        w.lm_head = torch.empty((4096, dims.hidden_size), device=dev, dtype=BF16).normal_(0, 0.02, generator=gen)
+        w.embed_tokens = torch.empty((4096, dims.hidden_size), device=dev, dtype=BF16).normal_(0, 0.02, generator=gen)
+    ctx = 400
+    past = synthetic_context(dims, 1, ctx, dev, 5)
+    gi = model.prepare_start_tokens([ctx], [ctx], IDS)
+    logits = []
+    toks = model.generate_text(past_key_values=past, max_length=300, do_sample=False, logits_trace=logits, **gi)
+    toks2 = model.generate_text(past_key_values=past, max_length=300, do_sample=False, **gi)
+    short = model.generate_text(past_key_values=past, max_length=100, do_sample=False, **gi)
+    assert toks.shape == (300, 1) and int(toks[0, 0]) == IDS["bos_token_id"]
+    assert torch.equal(toks, toks2) and torch.equal(short, toks[:100])
+    assert all(torch.isfinite(l.float()).all() for l in logits[::50])
+    assert len(set(toks[:, 0].tolist())) > 3            # not stuck on one token from the first step
+    # push the text back (inferencer.py:299-301) and generate over the 702-token context
+    text = " ".join(str(int(t)) for t in toks[1:, 0].tolist())
+    gp, kv, rope = model.prepare_prompts([ctx], [ctx], [text], _Tok(), IDS)
+    past = model.forward_cache_update_text(past, **gp)
+    assert kv == [ctx + 299 + 2] and past.key_cache[0].shape[0] == kv[0]
+    res = (1024, 1024)
+    torch.manual_seed(3)
+    g0 = model.prepare_vae_latent(kv, rope, [res], IDS)
+    gt = model.prepare_vae_latent_cfg([0], [0], [res])
+    gm = model.prepare_vae_latent_cfg(kv, rope, [res])
+    from bagel_amd.modeling import NaiveCache
+
+    def run(trace):
+        return model.generate_image(
+            past_key_values=past, num_timesteps=50, timestep_shift=3.0, cfg_renorm_type="global", cfg_interval=[0.4, 1.0],
+            cfg_text_scale=4.0, cfg_text_past_key_values=NaiveCache(dims.num_layers),
+            cfg_text_packed_position_ids=gt["cfg_packed_position_ids"],
+            cfg_text_packed_query_indexes=gt["cfg_packed_query_indexes"], cfg_text_key_values_lens=gt["cfg_key_values_lens"],
+            cfg_text_packed_key_value_indexes=gt["cfg_packed_key_value_indexes"], cfg_img_scale=1.5,
+            cfg_img_past_key_values=past, cfg_img_packed_position_ids=gm["cfg_packed_position_ids"],
+            cfg_img_packed_query_indexes=gm["cfg_packed_query_indexes"], cfg_img_key_values_lens=gm["cfg_key_values_lens"],
+            cfg_img_packed_key_value_indexes=gm["cfg_packed_key_value_indexes"], max_steps=2, trace=trace, **g0)
+
+    ta, tb = [], []
+    la, lb = run(ta), run(tb)
+    assert torch.equal(la[0], lb[0]) and torch.isfinite(la[0]).all()
+    for ra, rb in zip(ta, tb):
+        for k in ra:
+            assert torch.equal(ra[k], rb[k]), k
+    assert torch.equal(ta[0]["v_img"], ta[0]["v_cond"])      # same context, same RoPE position -> same velocity

@@ -64,3 +64,21 @@ for _ in range(R):
     K.gemm(Hm, Wd, X, residual=X, epilogue=K.EPI_RESIDUAL)
 torch.cuda.synchronize()
 print("done")
+
+if os.environ.get("PMC_SKINNY") == "1":
+    # the understanding expert's weight-streaming projections of the same step (6 text rows) and the timestep MLP
+    print("skinny section", flush=True)
+    Mt = 6
+    ws = torch.empty((16 * 64 * 2 * I,), device=dev, dtype=torch.float32)
+    xs = rn(Mt, H)
+    for name, W_, out_cols, epi in (("qkv", Wqkv, 4608, K.SK_BIAS), ("gate_up", Wgu, I, K.SK_SWIGLU)):
+        out = torch.empty((Mt, out_cols), device=dev, dtype=BF)
+        for _ in range(R):
+            K.skinny_gemm(xs, W_, out, ws, bias=bqkv if epi == K.SK_BIAS else None, epilogue=epi)
+        torch.cuda.synchronize()
+        print("skinny", name, "ok", flush=True)
+    hs = rn(Mt, I)
+    for _ in range(R):
+        K.skinny_gemm(hs, Wd, xs, ws, residual=xs, epilogue=K.SK_RESIDUAL)
+    torch.cuda.synchronize()
+    print("skinny down ok", flush=True)
