@@ -277,6 +277,18 @@ def cfg_euler_update(v_cond, v_text, v_img, cfg_text_scale, cfg_img_scale, renor
            "bagel_cfg_euler_update")
 
 
+def cfg_euler_update_static(v_cond, v_text, v_img, cfg_text_scale, cfg_img_scale, renorm_type, renorm_min, dt, x_t,
+                            x_bf16, v_t_out):
+    """cfg_euler_update on the library's built-in scratch: no workspace, no allocation (rows <= 65536)."""
+    if renorm_type not in RENORM:
+        raise NotImplementedError(f"{renorm_type} is not suppoprted")
+    rows, P = x_t.shape
+    _check(lib().bagel_cfg_euler_update_static(_p(v_cond), _p(v_text), _p(v_img), F(cfg_text_scale), F(cfg_img_scale),
+                                               I(RENORM[renorm_type]), F(renorm_min), F(dt), _p(x_t), _p(x_bf16),
+                                               _p(v_t_out), I(rows), I(P), _stream()),
+           "bagel_cfg_euler_update_static")
+
+
 # ---- FLUX VAE decoder ---------------------------------------------------------------------------
 def conv3x3(x, Hin, Win, Cin, w, bias, out, zero_page, upsample=False, residual=None, downsample=False):
     Cout = w.shape[0]

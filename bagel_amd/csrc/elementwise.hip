@@ -471,18 +471,18 @@ __global__ __launch_bounds__(256) void euler_update_kernel(const bf16* __restric
 
 extern "C" long bagel_cfg_workspace_bytes(int rows, int P) { return ((long)rows * P * 2 + 2L * rows * 4 + 256 + 255) / 256 * 256; }
 
-extern "C" int bagel_cfg_euler_update(const void* v_cond, const void* v_text, const void* v_img, float cfg_text_scale,
-                                      float cfg_img_scale, int renorm_type, float renorm_min, float dt, void* x_t,
-                                      void* x_bf16, void* v_t_out, int rows, int P, void* workspace,
-                                      long workspace_bytes, void* stream) {
-  BAGEL_CHECK(v_cond && x_t && x_bf16 && workspace, "bagel_cfg_euler_update: null operand");
-  BAGEL_CHECK(rows > 0 && P == 64, "bagel_cfg_euler_update: rows=%d P=%d (P must be 64)", rows, P);
-  BAGEL_CHECK(renorm_type >= 0 && renorm_type <= 2, "bagel_cfg_euler_update: cfg_renorm_type %d is not supported", renorm_type);
-  BAGEL_CHECK(workspace_bytes >= bagel_cfg_workspace_bytes(rows, P), "bagel_cfg_euler_update: workspace too small");
+// Shared by both entry points below; `workspace` holds bagel_cfg_workspace_bytes(rows, P) bytes.  Every word of the
+// workspace that is read has been written earlier in the same call, so nothing has to start at zero.
+static int cfg_euler_launch(const char* who, const void* v_cond, const void* v_text, const void* v_img, float cfg_text_scale,
+                            float cfg_img_scale, int renorm_type, float renorm_min, float dt, void* x_t, void* x_bf16,
+                            void* v_t_out, int rows, int P, void* workspace, void* stream) {
+  BAGEL_CHECK(v_cond && x_t && x_bf16 && workspace, "%s: null operand", who);
+  BAGEL_CHECK(rows > 0 && P == 64, "%s: rows=%d P=%d (P must be 64)", who, rows, P);
+  BAGEL_CHECK(renorm_type >= 0 && renorm_type <= 2, "%s: cfg_renorm_type %d is not supported", who, renorm_type);
   const bool cfg = cfg_text_scale > 1.0f;  // bagel.py:1466: image CFG only ever acts together with text CFG
   if (cfg) {
-    BAGEL_CHECK(v_text, "bagel_cfg_euler_update: cfg_text_scale > 1 needs v_text");
-    BAGEL_CHECK(!(cfg_img_scale > 1.0f) || v_img, "bagel_cfg_euler_update: cfg_img_scale > 1 needs v_img");
+    BAGEL_CHECK(v_text, "%s: cfg_text_scale > 1 needs v_text", who);
+    BAGEL_CHECK(!(cfg_img_scale > 1.0f) || v_img, "%s: cfg_img_scale > 1 needs v_img", who);
   }
   hipStream_t st = (hipStream_t)stream;
   const long n = (long)rows * P;
@@ -506,6 +506,66 @@ extern "C" int bagel_cfg_euler_update(const void* v_cond, const void* v_text, co
                      (float*)x_t, (bf16*)x_bf16, (bf16*)v_t_out, n);
   BAGEL_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int bagel_cfg_euler_update(const void* v_cond, const void* v_text, const void* v_img, float cfg_text_scale,
+                                      float cfg_img_scale, int renorm_type, float renorm_min, float dt, void* x_t,
+                                      void* x_bf16, void* v_t_out, int rows, int P, void* workspace,
+                                      long workspace_bytes, void* stream) {
+  BAGEL_CHECK(workspace, "bagel_cfg_euler_update: null operand");
+  BAGEL_CHECK(rows > 0 && P == 64, "bagel_cfg_euler_update: rows=%d P=%d (P must be 64)", rows, P);
+  BAGEL_CHECK(workspace_bytes >= bagel_cfg_workspace_bytes(rows, P), "bagel_cfg_euler_update: workspace too small");
+  return cfg_euler_launch("bagel_cfg_euler_update", v_cond, v_text, v_img, cfg_text_scale, cfg_img_scale, renorm_type,
+                          renorm_min, dt, x_t, x_bf16, v_t_out, rows, P, workspace, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same update for callers that cannot allocate (a step loop under HIP graph capture, a serving loop that
+// forbids hipMalloc): the pre-renorm velocity, the per-row sums of squares and the global scale live in a
+// file-scope device array instead of a caller workspace.  One array per GPU, held until the process ends;
+// its device address is looked up once per device and only that address is ever handed to kernels.
+// ---------------------------------------------------------------------------------------------
+constexpr int CFG_STATIC_MAX_ROWS = 65536;  // 16 images of 1024 x 1024 (4096 latent tokens each)
+constexpr long CFG_STATIC_BYTES = ((long)CFG_STATIC_MAX_ROWS * 64 * 2 + 2L * CFG_STATIC_MAX_ROWS * 4 + 256 + 255) / 256 * 256;
+static __device__ __align__(256) unsigned char scratch[CFG_STATIC_BYTES];
+
+#include <mutex>
+static int cfg_static_scratch(void** out) {
+  static std::mutex mu;
+  static void* ptr_of_device[64] = {nullptr};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= 64) {
+    bagel_set_error("bagel_cfg_euler_update_static: hipGetDevice failed or device ordinal %d beyond 63: %s", dev,
+                    hipGetErrorString(e));
+    return 2;
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  if (ptr_of_device[dev] == nullptr) {
+    void* ptr = nullptr;
+    e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));   // this device's copy of the array (dev is current)
+    if (e != hipSuccess || ptr == nullptr) {
+      bagel_set_error("bagel_cfg_euler_update_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+      return 2;
+    }
+    ptr_of_device[dev] = ptr;
+  }
+  *out = ptr_of_device[dev];
+  return 0;
+}
+
+extern "C" int bagel_cfg_static_max_rows(void) { return CFG_STATIC_MAX_ROWS; }
+
+extern "C" int bagel_cfg_euler_update_static(const void* v_cond, const void* v_text, const void* v_img, float cfg_text_scale,
+                                             float cfg_img_scale, int renorm_type, float renorm_min, float dt, void* x_t,
+                                             void* x_bf16, void* v_t_out, int rows, int P, void* stream) {
+  BAGEL_CHECK(rows > 0 && P == 64, "bagel_cfg_euler_update_static: rows=%d P=%d (P must be 64)", rows, P);
+  BAGEL_CHECK(rows <= CFG_STATIC_MAX_ROWS, "bagel_cfg_euler_update_static: rows=%d exceeds the built-in scratch (%d rows); "
+              "use bagel_cfg_euler_update with a caller workspace", rows, CFG_STATIC_MAX_ROWS);
+  void* ws = nullptr;
+  if (int rc = cfg_static_scratch(&ws)) return rc;
+  return cfg_euler_launch("bagel_cfg_euler_update_static", v_cond, v_text, v_img, cfg_text_scale, cfg_img_scale, renorm_type,
+                          renorm_min, dt, x_t, x_bf16, v_t_out, rows, P, ws, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

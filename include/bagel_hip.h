@@ -87,7 +87,10 @@ int bagel_qk_norm_rope_kv_bf16(const void* qkv, long ld, int M, int Hq, int Hkv,
  * causal_base >= 0, row r of the tile only sees the first causal_base + r + 1 of them (the bottom-right
  * aligned causal mask of flash-attn >= 2.1; causal_base = context length + index of the tile's first row
  * among the sample's new tokens).  causal_base = -1 for the non-causal generation forward.
- * S (key slots per kv head, a multiple of 64) is limited to S * head_dim * 2 < 2^31 bytes. */
+ * S (key slots per kv head, a multiple of 64) is limited to S * head_dim * 2 < 2^31 bytes.
+ * Precondition: keys are consumed in tiles of 64 slots, so the slots from kv_start + kv_len up to the next
+ * multiple of 64 are read.  Their scores are replaced by -inf (K_ws may hold anything there), but their zero
+ * probabilities still multiply Vt_ws: those Vt_ws slots must hold FINITE values (0 x NaN is NaN). */
 int bagel_varlen_attention_bf16(const void* Q, const void* K_ws, const void* Vt_ws, void* O, const void* tiles,
                                 int n_tiles, int Hq, int Hkv, int head_dim, long S, void* stream);
 
@@ -144,6 +147,19 @@ long bagel_cfg_workspace_bytes(int rows, int P);
 int bagel_cfg_euler_update(const void* v_cond, const void* v_text, const void* v_img, float cfg_text_scale,
                            float cfg_img_scale, int renorm_type, float renorm_min, float dt, void* x_t, void* x_bf16,
                            void* v_t_out, int rows, int P, void* workspace, long workspace_bytes, void* stream);
+
+/* bagel_cfg_euler_update without a workspace argument and without any allocation.  No counterpart in the
+ * reference: it exists for callers that cannot allocate device memory (a flow-step loop under HIP graph capture,
+ * serving loops and harnesses that forbid hipMalloc).  The scratch (pre-renorm velocity, per-row sums of squares,
+ * global scale: 8.5 MiB) is a file-scope device array of the library, one copy per GPU, held until the process
+ * ends.  rows <= bagel_cfg_static_max_rows() (65536 = 16 images of 1024x1024), otherwise an error is returned.
+ * Results are bit-identical to bagel_cfg_euler_update.  Every word of the scratch that a call reads it has written
+ * first, so nothing is cleared between calls; all calls on one GPU share the array, so calls that overlap on
+ * one GPU (different streams) race - serialise them. */
+int bagel_cfg_static_max_rows(void);
+int bagel_cfg_euler_update_static(const void* v_cond, const void* v_text, const void* v_img, float cfg_text_scale,
+                                  float cfg_img_scale, int renorm_type, float renorm_min, float dt, void* x_t,
+                                  void* x_bf16, void* v_t_out, int rows, int P, void* stream);
 
 /* ---- FLUX VAE decoder (modeling/autoencoder.py:196-272, 320-322); activations are NHWC bf16 ---- */
 
