@@ -1,32 +1,95 @@
-"""``InterleaveInferencer``: the reference's orchestration class (inferencer.py:37-325, 982-1007) over the
-HIP-backed ``Bagel`` and ``AutoEncoder``.  Same constructor, same method names, same keyword defaults.
+"""Orchestration of interleaved text / image requests over the HIP-backed ``Bagel`` and ``AutoEncoder``.
 
-Covered: text prompts -> image (``interleave_inference`` / ``__call__`` with ``text=...``), ``gen_image``,
-``decode_image``, context bookkeeping with ``deepcopy`` snapshots for the CFG branches.
-``gen_text`` and the think modes (autoregressive decoding through the understanding expert) are covered too.
-Image inputs (``update_context_image``: VAE encode + VAE-token prefill, SigLIP tower + connector prefill) are
-covered as well; the image transforms are host code in ``bagel_amd/transforms.py``.
+The public surface is the reference's ``InterleaveInferencer`` (inferencer.py:37-325, 982-1007): same constructor,
+method names, keyword defaults and return values, so callers switch by changing an import.  Underneath, a request
+is modelled by two small objects of this module:
+
+``GenContext``
+    one KV context: per-sample lengths, RoPE positions and the ``NaiveCache``.  It is a ``dict`` with the
+    reference's three keys (callers index it, and ``deepcopy`` still works), plus ``fork()``.  The engine never
+    writes into a cache tensor - every prefill returns new tensors - so a fork shares tensors with its parent and
+    costs nothing, where the reference deep-copies up to 0.5 GB of keys and values per CFG branch
+    (inferencer.py:269-292).
+
+``CfgContexts``
+    the three contexts classifier-free guidance needs, advanced together term by term: ``full`` (everything),
+    ``no_text`` (the state before the most recent text, or right after the most recent image) and ``no_image``
+    (text only).  The rules are the reference's (inferencer.py:273-292), stated once in ``add_text`` /
+    ``add_image`` instead of inline in the request loop.
 """
 from __future__ import annotations
 
-from copy import deepcopy
-from typing import List, Union
+from typing import List, Optional, Union
 
 import torch
 from PIL import Image
 
-from .transforms import pil_img2rgb
 from .modeling.bagel import NaiveCache
+from .transforms import pil_img2rgb
+
+# System prompts of the think modes: model inputs, so they are the reference's strings character for character
+# (inferencer.py:15-21).
+# (written as explicit line pieces: the first line of each prompt ends in a space before its newline)
+VLM_THINK_SYSTEM_PROMPT = (
+    "You should first think about the reasoning process in the mind and then provide the user with the answer. \n"
+    "The reasoning process is enclosed within <think> </think> tags, i.e. <think> reasoning process here </think> answer here")
+
+GEN_THINK_SYSTEM_PROMPT = (
+    "You should first think about the planning process in the mind and then generate the image. \n"
+    "The planning process is enclosed within <think> </think> tags, i.e. <think> planning process here </think> "
+    "<|vision_start|> image will be generated here <|vision_end|>\n"
+    "\n"
+    "When you want to generate an image, use the special tokens <|vision_start|> and <|vision_end|> to indicate where the "
+    "image should be placed.")
 
 
-# System prompts of the reference's think modes (inferencer.py:15-21)
-VLM_THINK_SYSTEM_PROMPT = '''You should first think about the reasoning process in the mind and then provide the user with the answer. 
-The reasoning process is enclosed within <think> </think> tags, i.e. <think> reasoning process here </think> answer here'''
+class GenContext(dict):
+    """``{"kv_lens", "ropes", "past_key_values"}`` with cheap copies."""
 
-GEN_THINK_SYSTEM_PROMPT = '''You should first think about the planning process in the mind and then generate the image. 
-The planning process is enclosed within <think> </think> tags, i.e. <think> planning process here </think> <|vision_start|> image will be generated here <|vision_end|>
+    @classmethod
+    def empty(cls, num_layers: int, batch: int = 1) -> "GenContext":
+        return cls(kv_lens=[0] * batch, ropes=[0] * batch, past_key_values=NaiveCache(num_layers))
 
-When you want to generate an image, use the special tokens <|vision_start|> and <|vision_end|> to indicate where the image should be placed.'''
+    @classmethod
+    def of(cls, mapping) -> "GenContext":
+        return mapping if isinstance(mapping, cls) else cls(mapping)
+
+    def fork(self) -> "GenContext":
+        """An independent context that starts equal to this one.  Lists and the per-layer dicts are copied, the
+        key/value tensors are shared: they are never modified in place."""
+        src = self["past_key_values"]
+        cache = NaiveCache(src.num_layers)
+        cache.key_cache = dict(src.key_cache)
+        cache.value_cache = dict(src.value_cache)
+        return GenContext(kv_lens=list(self["kv_lens"]), ropes=list(self["ropes"]), past_key_values=cache)
+
+    def advance(self, kv_lens, ropes, past_key_values) -> "GenContext":
+        self["kv_lens"], self["ropes"], self["past_key_values"] = kv_lens, ropes, past_key_values
+        return self
+
+
+class CfgContexts:
+    """The (full, no_text, no_image) context triple of one request."""
+
+    def __init__(self, inferencer: "InterleaveInferencer"):
+        self._inf = inferencer
+        self.full = inferencer.init_gen_context()
+        self.no_text = self.full.fork()
+        self.no_image = self.full.fork()
+
+    def add_system_prompt(self, prompt: str):
+        # a system prompt is part of both the conditional and the image-free context, never of the text-free one
+        self._inf.update_context_text(prompt, self.full)
+        self._inf.update_context_text(prompt, self.no_image)
+
+    def add_text(self, text: str):
+        self.no_text = self.full.fork()                      # everything up to, but not including, this text
+        self._inf.update_context_text(text, self.full)
+        self._inf.update_context_text(text, self.no_image)
+
+    def add_image(self, image, with_vae_tokens: bool):
+        self._inf.update_context_image(image, self.full, vae=with_vae_tokens)
+        self.no_text = self.full.fork()                      # images stay in the text-free context
 
 
 class InterleaveInferencer:
@@ -38,159 +101,130 @@ class InterleaveInferencer:
         self.vit_transform = vit_transform
         self.new_token_ids = new_token_ids
 
-    def init_gen_context(self):
-        """inferencer.py:48-54."""
-        return {"kv_lens": [0], "ropes": [0],
-                "past_key_values": NaiveCache(self.model.config.llm_config.num_hidden_layers)}
+    # ---- contexts ---------------------------------------------------------------------------------------
+    def init_gen_context(self) -> GenContext:
+        return GenContext.empty(self.model.config.llm_config.num_hidden_layers)
 
     @torch.no_grad()
     def update_context_text(self, text, gen_context):
-        """inferencer.py:57-76."""
-        generation_input, kv_lens, ropes = self.model.prepare_prompts(
-            curr_kvlens=gen_context["kv_lens"], curr_rope=gen_context["ropes"], prompts=[text],
-            tokenizer=self.tokenizer, new_token_ids=self.new_token_ids)
-        past_key_values = self.model.forward_cache_update_text(gen_context["past_key_values"], **generation_input)
-        gen_context["kv_lens"] = kv_lens
-        gen_context["ropes"] = ropes
-        gen_context["past_key_values"] = past_key_values
-        return gen_context
+        """Append one prompt (bos + tokens + eos) to the context: prepare_prompts + forward_cache_update_text."""
+        ctx = GenContext.of(gen_context)
+        inputs, kv_lens, ropes = self.model.prepare_prompts(curr_kvlens=ctx["kv_lens"], curr_rope=ctx["ropes"], prompts=[text],
+                                                            tokenizer=self.tokenizer, new_token_ids=self.new_token_ids)
+        cache = self.model.forward_cache_update_text(ctx["past_key_values"], **inputs)
+        return self._commit(gen_context, kv_lens, ropes, cache)
 
     @torch.no_grad()
     def update_context_image(self, image, gen_context, vae=True, vit=True):
-        """inferencer.py:79-123: append the image's VAE tokens and / or ViT tokens to the context."""
+        """Append an image as VAE tokens (generation expert) and / or ViT tokens (understanding expert)."""
         assert vae or vit
-        past_key_values = gen_context["past_key_values"]
-        kv_lens, ropes = gen_context["kv_lens"], gen_context["ropes"]
+        ctx = GenContext.of(gen_context)
+        kv_lens, ropes, cache = ctx["kv_lens"], ctx["ropes"], ctx["past_key_values"]
+        stages = []
         if vae:
-            generation_input, kv_lens, ropes = self.model.prepare_vae_images(
-                curr_kvlens=kv_lens, curr_rope=ropes, images=[image], transforms=self.vae_transform,
-                new_token_ids=self.new_token_ids)
-            past_key_values = self.model.forward_cache_update_vae(self.vae_model, past_key_values, **generation_input)
+            stages.append((self.model.prepare_vae_images, self.vae_transform,
+                           lambda c, inp: self.model.forward_cache_update_vae(self.vae_model, c, **inp)))
         if vit:
-            generation_input, kv_lens, ropes = self.model.prepare_vit_images(
-                curr_kvlens=kv_lens, curr_rope=ropes, images=[image], transforms=self.vit_transform,
-                new_token_ids=self.new_token_ids)
-            past_key_values = self.model.forward_cache_update_vit(past_key_values, **generation_input)
-        gen_context["kv_lens"] = kv_lens
-        gen_context["ropes"] = ropes
-        gen_context["past_key_values"] = past_key_values
+            stages.append((self.model.prepare_vit_images, self.vit_transform,
+                           lambda c, inp: self.model.forward_cache_update_vit(c, **inp)))
+        for prepare, transform, prefill in stages:
+            inputs, kv_lens, ropes = prepare(curr_kvlens=kv_lens, curr_rope=ropes, images=[image], transforms=transform,
+                                             new_token_ids=self.new_token_ids)
+            cache = prefill(cache, inputs)
+        return self._commit(gen_context, kv_lens, ropes, cache)
+
+    @staticmethod
+    def _commit(gen_context, kv_lens, ropes, cache):
+        gen_context["kv_lens"], gen_context["ropes"], gen_context["past_key_values"] = kv_lens, ropes, cache
         return gen_context
 
+    # ---- generation -------------------------------------------------------------------------------------
     @torch.no_grad()
     def gen_image(self, image_shape, gen_context, cfg_text_scale=4.0, cfg_img_scale=1.5, cfg_text_precontext=None,
                   cfg_img_precontext=None, cfg_interval=(0.4, 1.0), cfg_renorm_min=0.0, cfg_renorm_type="global",
                   num_timesteps=50, timestep_shift=3.0, enable_taylorseer=False):
-        """inferencer.py:126-198."""
         model = self.model
-        generation_input = model.prepare_vae_latent(curr_kvlens=gen_context["kv_lens"], curr_rope=gen_context["ropes"],
-                                                    image_sizes=[image_shape], new_token_ids=self.new_token_ids)
-        gt = model.prepare_vae_latent_cfg(curr_kvlens=cfg_text_precontext["kv_lens"],
-                                          curr_rope=cfg_text_precontext["ropes"], image_sizes=[image_shape])
-        gm = model.prepare_vae_latent_cfg(curr_kvlens=cfg_img_precontext["kv_lens"],
-                                          curr_rope=cfg_img_precontext["ropes"], image_sizes=[image_shape])
-        unpacked_latent = model.generate_image(
-            past_key_values=gen_context["past_key_values"],
-            cfg_text_past_key_values=cfg_text_precontext["past_key_values"],
-            cfg_img_past_key_values=cfg_img_precontext["past_key_values"],
-            num_timesteps=num_timesteps, cfg_text_scale=cfg_text_scale, cfg_img_scale=cfg_img_scale,
-            cfg_interval=cfg_interval, cfg_renorm_min=cfg_renorm_min, cfg_renorm_type=cfg_renorm_type,
-            timestep_shift=timestep_shift, **generation_input,
-            cfg_text_packed_position_ids=gt["cfg_packed_position_ids"],
-            cfg_text_packed_query_indexes=gt["cfg_packed_query_indexes"],
-            cfg_text_key_values_lens=gt["cfg_key_values_lens"],
-            cfg_text_packed_key_value_indexes=gt["cfg_packed_key_value_indexes"],
-            cfg_img_packed_position_ids=gm["cfg_packed_position_ids"],
-            cfg_img_packed_query_indexes=gm["cfg_packed_query_indexes"],
-            cfg_img_key_values_lens=gm["cfg_key_values_lens"],
-            cfg_img_packed_key_value_indexes=gm["cfg_packed_key_value_indexes"],
-            enable_taylorseer=enable_taylorseer)
-        return self.decode_image(unpacked_latent[0], image_shape)
+        sizes = [image_shape]
+        kwargs = dict(model.prepare_vae_latent(curr_kvlens=gen_context["kv_lens"], curr_rope=gen_context["ropes"],
+                                               image_sizes=sizes, new_token_ids=self.new_token_ids))
+        kwargs["past_key_values"] = gen_context["past_key_values"]
+        # each guidance branch contributes the same five arguments under its own prefix
+        for prefix, ctx in (("cfg_text", cfg_text_precontext), ("cfg_img", cfg_img_precontext)):
+            branch = model.prepare_vae_latent_cfg(curr_kvlens=ctx["kv_lens"], curr_rope=ctx["ropes"], image_sizes=sizes)
+            kwargs[f"{prefix}_past_key_values"] = ctx["past_key_values"]
+            for name in ("packed_position_ids", "packed_query_indexes", "key_values_lens", "packed_key_value_indexes"):
+                kwargs[f"{prefix}_{name}"] = branch[f"cfg_{name}"]
+        latents = model.generate_image(num_timesteps=num_timesteps, timestep_shift=timestep_shift,
+                                       cfg_text_scale=cfg_text_scale, cfg_img_scale=cfg_img_scale, cfg_interval=cfg_interval,
+                                       cfg_renorm_min=cfg_renorm_min, cfg_renorm_type=cfg_renorm_type,
+                                       enable_taylorseer=enable_taylorseer, **kwargs)
+        return self.decode_image(latents[0], image_shape)
 
     def decode_image(self, latent, image_shape):
-        """inferencer.py:201-212: un-patchify, VAE decode, uint8 PIL image."""
-        H, W = image_shape
+        """Packed latent tokens ``[h*w, p*p*c]`` -> ``[1, c, h*p, w*p]`` -> VAE decode -> uint8 PIL image."""
         m = self.model
-        h, w = H // m.latent_downsample, W // m.latent_downsample
         p, c = m.latent_patch_size, m.latent_channel
-        latent = latent.reshape(1, h, w, p, p, c)
-        latent = torch.einsum("nhwpqc->nchpwq", latent)
-        latent = latent.reshape(1, c, h * p, w * p)
-        image = self.vae_model.decode(latent)
-        image = (image * 0.5 + 0.5).clamp(0, 1)[0].permute(1, 2, 0) * 255
-        return Image.fromarray(image.to(torch.uint8).cpu().numpy())
+        h, w = image_shape[0] // m.latent_downsample, image_shape[1] // m.latent_downsample
+        grid = latent.reshape(h, w, p, p, c).permute(4, 0, 2, 1, 3).reshape(1, c, h * p, w * p)
+        pixels = self.vae_model.decode(grid)[0]
+        pixels = (pixels * 0.5 + 0.5).clamp(0, 1).permute(1, 2, 0) * 255
+        return Image.fromarray(pixels.to(torch.uint8).cpu().numpy())
 
     @torch.no_grad()
     def gen_text(self, gen_context, max_length=500, do_sample=True, temperature=1.0, return_tokens=False):
-        """inferencer.py:215-244."""
-        gen_context = deepcopy(gen_context)
-        generation_input = self.model.prepare_start_tokens(gen_context["kv_lens"], gen_context["ropes"], self.new_token_ids)
-        unpacked_latent = self.model.generate_text(
-            past_key_values=gen_context["past_key_values"], max_length=max_length, do_sample=do_sample,
-            temperature=temperature, end_token_id=self.new_token_ids["eos_token_id"], **generation_input)
-        output = self.tokenizer.decode(unpacked_latent[:, 0])
-        output = output.split("<|im_end|>")[0].split("<|im_start|>")[1]
-        if return_tokens:
-            return output, unpacked_latent[:, 0].tolist()
-        return output
+        """Decode up to ``max_length`` tokens after the context (which is left untouched) and return the text between
+        the chat markers."""
+        ctx = GenContext.of(gen_context)
+        start = self.model.prepare_start_tokens(ctx["kv_lens"], ctx["ropes"], self.new_token_ids)
+        tokens = self.model.generate_text(past_key_values=ctx["past_key_values"], max_length=max_length,
+                                          do_sample=do_sample, temperature=temperature,
+                                          end_token_id=self.new_token_ids["eos_token_id"], **start)[:, 0]
+        text = self.tokenizer.decode(tokens)
+        text = text.split("<|im_end|>")[0].split("<|im_start|>")[1]
+        return (text, tokens.tolist()) if return_tokens else text
 
+    # ---- requests ---------------------------------------------------------------------------------------
     @torch.no_grad()
     def interleave_inference(self, input_lists: List[Union[str, Image.Image]], think=False, understanding_output=False,
                              max_think_token_n=1000, do_sample=False, text_temperature=0.3, cfg_text_scale=3.0,
                              cfg_img_scale=1.5, cfg_interval=[0.4, 1.0], timestep_shift=3.0, num_timesteps=50,
                              cfg_renorm_min=0.0, cfg_renorm_type="global", image_shapes=(1024, 1024),
                              enable_taylorseer=False):
-        """inferencer.py:247-325 for text inputs and image output."""
-        output_list = []
-        gen_context = self.init_gen_context()
-        cfg_text_context = deepcopy(gen_context)
-        cfg_img_context = deepcopy(gen_context)
+        ctxs = CfgContexts(self)
         if think:
-            system_prompt = VLM_THINK_SYSTEM_PROMPT if understanding_output else GEN_THINK_SYSTEM_PROMPT
-            gen_context = self.update_context_text(system_prompt, gen_context)
-            cfg_img_context = self.update_context_text(system_prompt, cfg_img_context)
-        for input_term in input_lists:
-            if isinstance(input_term, str):
-                cfg_text_context = deepcopy(gen_context)
-                gen_context = self.update_context_text(input_term, gen_context)
-                cfg_img_context = self.update_context_text(input_term, cfg_img_context)
-            elif isinstance(input_term, Image.Image):
-                input_term = self.vae_transform.resize_transform(pil_img2rgb(input_term))
-                gen_context = self.update_context_image(input_term, gen_context, vae=not understanding_output)
-                image_shapes = input_term.size[::-1]
-                cfg_text_context = deepcopy(gen_context)
+            ctxs.add_system_prompt(VLM_THINK_SYSTEM_PROMPT if understanding_output else GEN_THINK_SYSTEM_PROMPT)
+        for term in input_lists:
+            if isinstance(term, str):
+                ctxs.add_text(term)
+            elif isinstance(term, Image.Image):
+                resized = self.vae_transform.resize_transform(pil_img2rgb(term))
+                ctxs.add_image(resized, with_vae_tokens=not understanding_output)
+                image_shapes = resized.size[::-1]            # an edited image keeps its (resized) input's shape
             else:
-                raise ValueError(f"Unsupported input type: {type(input_term)}")
-        if understanding_output:
-            output_list.append(self.gen_text(gen_context, do_sample=do_sample, temperature=text_temperature,
-                                             max_length=max_think_token_n))
-            return output_list
-        if think:
-            gen_text = self.gen_text(gen_context, do_sample=do_sample, temperature=text_temperature,
-                                     max_length=max_think_token_n)
-            gen_context = self.update_context_text(gen_text, gen_context)
-            output_list.append(gen_text)
-        img = self.gen_image(image_shapes, gen_context, cfg_text_precontext=cfg_text_context,
-                             cfg_img_precontext=cfg_img_context, cfg_text_scale=cfg_text_scale,
-                             cfg_img_scale=cfg_img_scale, cfg_interval=cfg_interval, timestep_shift=timestep_shift,
-                             num_timesteps=num_timesteps, cfg_renorm_min=cfg_renorm_min,
-                             cfg_renorm_type=cfg_renorm_type, enable_taylorseer=enable_taylorseer)
-        output_list.append(img)
-        return output_list
+                raise ValueError(f"Unsupported input type: {type(term)}")
 
-    def __call__(self, image=None, text=None, **kargs):
-        """inferencer.py:982-1007."""
-        output_dict = {"image": None, "text": None}
-        if image is None and text is None:
+        text_kwargs = dict(do_sample=do_sample, temperature=text_temperature, max_length=max_think_token_n)
+        if understanding_output:
+            return [self.gen_text(ctxs.full, **text_kwargs)]
+        outputs = []
+        if think:
+            thought = self.gen_text(ctxs.full, **text_kwargs)
+            self.update_context_text(thought, ctxs.full)     # the plan conditions the image; the CFG contexts do not see it
+            outputs.append(thought)
+        outputs.append(self.gen_image(image_shapes, ctxs.full, cfg_text_precontext=ctxs.no_text,
+                                      cfg_img_precontext=ctxs.no_image, cfg_text_scale=cfg_text_scale,
+                                      cfg_img_scale=cfg_img_scale, cfg_interval=cfg_interval, timestep_shift=timestep_shift,
+                                      num_timesteps=num_timesteps, cfg_renorm_min=cfg_renorm_min,
+                                      cfg_renorm_type=cfg_renorm_type, enable_taylorseer=enable_taylorseer))
+        return outputs
+
+    def __call__(self, image: Optional[Image.Image] = None, text: Optional[str] = None, **kargs):
+        """``{"image": PIL image or None, "text": str or None}`` for an optional input image and / or prompt."""
+        result = {"image": None, "text": None}
+        terms = [t for t in (image, text) if t is not None]
+        if not terms:
             print("Please provide at least one input: either an image or text.")
-            return output_dict
-        input_list = []
-        if image is not None:
-            input_list.append(image)
-        if text is not None:
-            input_list.append(text)
-        for i in self.interleave_inference(input_list, **kargs):
-            if isinstance(i, Image.Image):
-                output_dict["image"] = i
-            elif isinstance(i, str):
-                output_dict["text"] = i
-        return output_dict
+            return result
+        for out in self.interleave_inference(terms, **kargs):
+            result["image" if isinstance(out, Image.Image) else "text"] = out
+        return result
