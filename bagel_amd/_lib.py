@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libbagel_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "bagel_hip.h")
-SOURCES = ["capi.hip", "gemm.hip", "skinny.hip", "attention.hip", "elementwise.hip", "vae.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "skinny.hip", "attention.hip", "elementwise.hip", "vae.hip", "layer.hip"]
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -259,6 +259,66 @@ def argmax_rows(logits, out):
     _check(lib().bagel_argmax_rows_bf16(_p(logits), L(logits.stride(0)), I(rows), I(n), _p(out), _stream()),
            "bagel_argmax_rows_bf16")
     return out
+
+
+# ---- one layer / the whole stack per call --------------------------------------------------------
+VP = ctypes.c_void_p
+
+
+class MotDims(ctypes.Structure):
+    _fields_ = [("hidden", I), ("intermediate", I), ("num_heads", I), ("num_kv_heads", I), ("head_dim", I), ("rms_eps", F)]
+
+
+class MotExpert(ctypes.Structure):
+    _fields_ = [(n, VP) for n in ("wqkv", "bqkv", "wo", "wgu", "wd", "ln_in", "ln_post", "q_norm", "k_norm")]
+
+
+class MotLayer(ctypes.Structure):
+    _fields_ = [("gen", MotExpert), ("und", MotExpert)]
+
+
+class MotRows(ctypes.Structure):
+    _fields_ = [("rows_gen", I), ("rows_und", I), ("X", VP), ("Xn", VP), ("QKV", VP), ("Q", VP), ("O", VP), ("Hm", VP),
+                ("cos_table", VP), ("sin_table", VP), ("row_cs", VP), ("row_slot", VP), ("tiles", VP), ("n_tiles", I),
+                ("S", L), ("skinny_ws", VP), ("skinny_ws_bytes", L), ("und_rounding", I)]
+
+
+def _addr(t):
+    return None if t is None else _p(t).value
+
+
+def mot_rows(rows_gen, rows_und, X, Xn, QKV, Q, O, Hm, cos_t, sin_t, row_cs, row_slot, tiles, n_tiles, S, skinny_ws,
+             und_rounding=False) -> MotRows:
+    """The per-forward argument block of mot_forward; the tensors must outlive the call."""
+    return MotRows(rows_gen, rows_und, _addr(X), _addr(Xn), _addr(QKV), _addr(Q), _addr(O), _addr(Hm), _addr(cos_t),
+                   _addr(sin_t), _addr(row_cs), _addr(row_slot), _addr(tiles), n_tiles, S, _addr(skinny_ws),
+                   skinny_ws.numel() * skinny_ws.element_size(), 1 if und_rounding else 0)
+
+
+def mot_forward(dims: MotDims, layers, n_layers, rows: MotRows, K_ws, Vt_ws, kv_only_last=False, final_norm_gen=None,
+                final_norm_und=None, final_norm_rows=0):
+    """All decoder layers in one call (bagel_mot_forward); K_ws / Vt_ws are [L, ...] workspaces."""
+    assert K_ws.stride(0) == Vt_ws.stride(0)
+    _check(lib().bagel_mot_forward(ctypes.byref(dims), layers, I(n_layers), ctypes.byref(rows), _p(K_ws), _p(Vt_ws),
+                                   L(K_ws.stride(0)), I(1 if kv_only_last else 0), _p(final_norm_gen), _p(final_norm_und),
+                                   I(final_norm_rows), _stream()), "bagel_mot_forward")
+
+
+def mot_layer_forward(dims: MotDims, layer: MotLayer, rows: MotRows, K_ws, Vt_ws, flags=0, next_norm_gen=None,
+                      next_norm_und=None):
+    _check(lib().bagel_mot_layer_forward(ctypes.byref(dims), ctypes.byref(layer), ctypes.byref(rows), _p(K_ws), _p(Vt_ws),
+                                         I(flags), _p(next_norm_gen), _p(next_norm_und), _stream()), "bagel_mot_layer_forward")
+
+
+def profile_gate_up(on: bool):
+    lib().bagel_profile_gate_up(I(1 if on else 0))
+
+
+def profile_collect(cap=1 << 16):
+    ms = (ctypes.c_double * cap)()
+    fl = (ctypes.c_double * cap)()
+    n = lib().bagel_profile_collect(ms, fl, I(cap))
+    return [(ms[i], fl[i]) for i in range(n)]
 
 
 def cfg_workspace_bytes(rows, P):

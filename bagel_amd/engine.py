@@ -56,6 +56,21 @@ class MoTWeights:
         self.pos_embed = None
         self.lm_head = None         # [vocab, H]; only text decoding needs it
 
+    def layer_table(self):
+        """The layers as the C array ``bagel_mot_layer[num_layers]`` that bagel_mot_forward walks (device addresses of
+        the tensors held by ``self.layers``; built once)."""
+        if getattr(self, "_layer_table", None) is None or len(self._layer_table) != len(self.layers):
+            table = (K.MotLayer * len(self.layers))()
+            for dst, lw in zip(table, self.layers):
+                for e, expert in ((0, dst.gen), (1, dst.und)):
+                    for name, t in (("wqkv", lw.wqkv[e]), ("bqkv", lw.bqkv[e]), ("wo", lw.wo[e]), ("wgu", lw.wgu[e]),
+                                    ("wd", lw.wd[e]), ("ln_in", lw.ln_in[e]), ("ln_post", lw.ln_post[e]),
+                                    ("q_norm", lw.qn[e]), ("k_norm", lw.kn[e])):
+                        assert t.is_contiguous()
+                        setattr(expert, name, t.data_ptr())
+            self._layer_table = table
+        return self._layer_table
+
     @classmethod
     def from_state_dict(cls, dims: BagelDims, sd: Dict[str, torch.Tensor], device) -> "MoTWeights":
         """``sd`` uses the reference's parameter names (the layout of ema.safetensors)."""
@@ -235,9 +250,8 @@ class MoTEngine:
         self.w = weights
         self.device = device
         self._buf: Dict[str, torch.Tensor] = {}
-        # when set to a list, every gen-expert gate+up GEMM launch is bracketed by HIP events on the launch
-        # stream and (start, end, algorithmic flops) is appended (used by bench.py for the roofline figure)
-        self.profile_events: Optional[list] = None
+        self._cdims = K.MotDims(dims.hidden_size, dims.intermediate_size, dims.num_heads, dims.num_kv_heads, dims.head_dim,
+                                dims.rms_norm_eps)
         self.kws = None
         self.vtws = None
 
@@ -318,10 +332,6 @@ class MoTEngine:
                 self.vtws[l, :, :, ks:ks + u.ctx_len].copy_(u.ctx_v[l].permute(1, 2, 0))
 
     # ---- the forward ----------------------------------------------------------------------
-    def _und_rows(self, fn, Mt):
-        for r0 in range(0, Mt, 64):
-            fn(r0, min(64, Mt - r0))
-
     def forward_gen(self, plan: GenPlan, x_bf16: torch.Tensor, temb: torch.Tensor, text_emb: torch.Tensor,
                     taylor: Optional["TaylorStep"] = None):
         """x_bf16 [rows of the packed latent, P], temb [H], text_emb [Mt, H] -> velocities [Mv, P] (bf16),
@@ -358,37 +368,15 @@ class MoTEngine:
         K.embed_latent(lin, temb, w.pos_embed, self._pos_id, plan.src_row, X, Mv)
         K.gather_rows(text_emb, None, X[Mv:], Mt)
 
-        for l, lw in enumerate(w.layers):
-            kws, vtws = self.kws[l], self.vtws[l]
-            K.rmsnorm(X, Xn, lw.ln_in[0], lw.ln_in[1], Mv, eps)
-            K.gemm(Xn, lw.wqkv[0], QKV, bias=lw.bqkv[0], M=Mv)
-            self._und_rows(lambda r0, n: K.skinny_gemm(Xn[Mv + r0:Mv + r0 + n], lw.wqkv[1], QKV[Mv + r0:Mv + r0 + n],
-                                                       skw, bias=lw.bqkv[1]), Mt)
-            K.qk_norm_rope_kv(QKV, M, Hq, Hkv, D, lw.qn[0], lw.qn[1], lw.kn[0], lw.kn[1], Mv, plan.cos, plan.sin,
-                              plan.row_cs, plan.row_slot, Q, kws, vtws, plan.S, eps)
-            K.varlen_attention(Q, kws, vtws, O, plan.tiles, plan.n_tiles, Hq, Hkv, D, plan.S)
-            K.gemm(O, lw.wo[0], X, residual=X, epilogue=K.EPI_RESIDUAL, M=Mv)
-            self._und_rows(lambda r0, n: K.skinny_gemm(O[Mv + r0:Mv + r0 + n], lw.wo[1], X[Mv + r0:Mv + r0 + n], skw,
-                                                       residual=X[Mv + r0:Mv + r0 + n], epilogue=K.SK_RESIDUAL), Mt)
-            K.rmsnorm(X, Xn, lw.ln_post[0], lw.ln_post[1], Mv, eps)
-            if self.profile_events is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                K.gemm(Xn, lw.wgu[0], Hm, epilogue=K.EPI_SWIGLU, M=Mv)
-                e1.record()
-                self.profile_events.append((e0, e1, 2.0 * Mv * 2 * I * H))
-            else:
-                K.gemm(Xn, lw.wgu[0], Hm, epilogue=K.EPI_SWIGLU, M=Mv)
-            self._und_rows(lambda r0, n: K.skinny_gemm(Xn[Mv + r0:Mv + r0 + n], lw.wgu[1], Hm[Mv + r0:Mv + r0 + n],
-                                                       skw, epilogue=K.SK_SWIGLU), Mt)
-            K.gemm(Hm, lw.wd[0], X, residual=X, epilogue=K.EPI_RESIDUAL, M=Mv)
-            self._und_rows(lambda r0, n: K.skinny_gemm(Hm[Mv + r0:Mv + r0 + n], lw.wd[1], X[Mv + r0:Mv + r0 + n], skw,
-                                                       residual=X[Mv + r0:Mv + r0 + n], epilogue=K.SK_RESIDUAL), Mt)
+        # all layers + the final norm of the latent rows in one C call (the text rows' outputs are never read,
+        # bagel.py:1426)
+        rows = K.mot_rows(Mv, Mt, X, Xn, QKV, Q, O, Hm, plan.cos, plan.sin, plan.row_cs, plan.row_slot, plan.tiles,
+                          plan.n_tiles, plan.S, skw)
+        K.mot_forward(self._cdims, w.layer_table(), len(w.layers), rows, self.kws, self.vtws, final_norm_gen=w.norm[0],
+                      final_norm_und=w.norm[1], final_norm_rows=Mv)
 
         if taylor is not None:
             K.taylor_update(X[:Mv], taylor.factors, taylor.n_factors, taylor.distance)
-        # final norm + llm2vae on the latent rows only (the text rows' outputs are never read, bagel.py:1426)
-        K.rmsnorm(X, Xn, w.norm[0], w.norm[1], Mv, eps, rows=Mv)
         K.gemm(Xn, w.l2v_w, Vout, bias=w.l2v_b, M=Mv)
         return Vout
 
@@ -407,18 +395,6 @@ class MoTEngine:
         return keys, values
 
     # ---- understanding-mode prefill (context KV build) ------------------------------------------
-    def _linear_und(self, x, w, out, bias=None, residual=None, kind="bias"):
-        """x [M, K] through one understanding-expert projection: weight-streaming path for M <= 64 rows,
-        MFMA tile GEMM otherwise."""
-        M = x.shape[0]
-        if M <= 64:
-            skw = self._get("skinny_ws", (16 * 64 * max(2 * self.dims.intermediate_size, self.dims.q_dim + 2 * self.dims.kv_dim),),
-                            dtype=torch.float32)
-            ep = {"bias": K.SK_BIAS, "residual": K.SK_RESIDUAL, "swiglu": K.SK_SWIGLU}[kind]
-            return K.skinny_gemm(x, w, out, skw, bias=bias, residual=residual, epilogue=ep)
-        ep = {"bias": K.EPI_BIAS, "residual": K.EPI_RESIDUAL, "swiglu": K.EPI_SWIGLU}[kind]
-        return K.gemm(x, w, out, bias=bias, residual=residual, epilogue=ep)
-
     def prefill_und(self, emb: torch.Tensor, lens: Sequence[int], pos0: Sequence[int], ctx_lens: Sequence[int],
                     ctx_k: Sequence[Optional[List[torch.Tensor]]], ctx_v: Sequence[Optional[List[torch.Tensor]]],
                     is_causal: bool = True, same_position: bool = False):
@@ -468,18 +444,11 @@ class MoTEngine:
         O = self._get("uO", (M, d.q_dim))
         Hm = self._get("uHm", (M, I))
         eps = d.rms_norm_eps
-        for l, lw in enumerate(w.layers):
-            K.rmsnorm(X, Xn, lw.ln_in[1], None, M, eps)
-            self._linear_und(Xn, lw.wqkv[1], QKV, bias=lw.bqkv[1])
-            K.qk_norm_rope_kv(QKV, M, Hq, Hkv, D, lw.qn[1], None, lw.kn[1], None, M, cos, sin, row_cs, row_slot, Q,
-                              kws[l], vtws[l], S, eps, und_rounding=True)
-            if l == L - 1:
-                break
-            K.varlen_attention(Q, kws[l], vtws[l], O, tiles_t, len(tiles), Hq, Hkv, D, S)
-            self._linear_und(O, lw.wo[1], X, residual=X, kind="residual")
-            K.rmsnorm(X, Xn, lw.ln_post[1], None, M, eps)
-            self._linear_und(Xn, lw.wgu[1], Hm, kind="swiglu")
-            self._linear_und(Hm, lw.wd[1], X, residual=X, kind="residual")
+        skw = self._get("skinny_ws", (16 * 64 * max(2 * I, qkv_dim),), dtype=torch.float32)
+        rows = K.mot_rows(0, M, X, Xn, QKV, Q, O, Hm, cos, sin, row_cs, row_slot, tiles_t, len(tiles), S, skw,
+                          und_rounding=True)
+        # the last layer's attention and MLP are skipped: only its keys/values are kept
+        K.mot_forward(self._cdims, w.layer_table(), L, rows, kws, vtws, kv_only_last=True)
         keys, values = [], []
         for l in range(L):
             keys.append(torch.cat([kws[l, :, ks:ks + c + n, :].permute(1, 0, 2) for ks, n, c in zip(kv_start, lens, ctx_lens)]).contiguous())
@@ -561,28 +530,12 @@ class MoTEngine:
         eps = d.rms_norm_eps
         Mt = M - Mv
 
-        def linear(x, out, wts, bias=None, residual=None, kind="bias"):
-            """One projection for both row blocks: generation expert on rows [0, Mv), understanding on the rest."""
-            ep = {"bias": K.EPI_BIAS, "residual": K.EPI_RESIDUAL, "swiglu": K.EPI_SWIGLU}[kind]
-            if Mv:
-                K.gemm(x, wts[0], out, bias=None if bias is None else bias[0], residual=residual, epilogue=ep, M=Mv)
-            if Mt:
-                self._linear_und(x[Mv:], wts[1], out[Mv:], bias=None if bias is None else bias[1],
-                                 residual=None if residual is None else residual[Mv:], kind=kind)
-
-        for l, lw in enumerate(w.layers):
-            K.rmsnorm(X, Xn, lw.ln_in[0], lw.ln_in[1], Mv, eps)
-            linear(Xn, QKV, lw.wqkv, bias=lw.bqkv)
-            # mode="und" rounds the normalised q/k and the RoPE products to bf16 (qwen2_navit.py:526-530), the
-            # mixed graph keeps them in fp32 until the final cast (:549-568)
-            K.qk_norm_rope_kv(QKV, M, Hq, Hkv, D, lw.qn[0], lw.qn[1], lw.kn[0], lw.kn[1], Mv, cos, sin, row_cs, row_slot, Q,
-                              kws[l], vtws[l], S, eps, und_rounding=gen_rows is None)
-            K.varlen_attention(Q, kws[l], vtws[l], O, tiles_t, len(tiles), Hq, Hkv, D, S)
-            linear(O, X, lw.wo, residual=X, kind="residual")
-            K.rmsnorm(X, Xn, lw.ln_post[0], lw.ln_post[1], Mv, eps)
-            linear(Xn, Hm, lw.wgu, kind="swiglu")
-            linear(Hm, X, lw.wd, residual=X, kind="residual")
-        K.rmsnorm(X, Xn, w.norm[0], w.norm[1], Mv, eps)
+        skw = self._get("skinny_ws", (16 * 64 * max(2 * I, qkv_dim),), dtype=torch.float32)
+        # mode="und" rounds the normalised q/k and the RoPE products to bf16 (qwen2_navit.py:526-530), the mixed graph
+        # keeps them in fp32 until the final cast (:549-568)
+        rows = K.mot_rows(Mv, Mt, X, Xn, QKV, Q, O, Hm, cos, sin, row_cs, row_slot, tiles_t, len(tiles), S, skw,
+                          und_rounding=gen_rows is None)
+        K.mot_forward(self._cdims, w.layer_table(), L, rows, kws, vtws, final_norm_gen=w.norm[0], final_norm_und=w.norm[1])
         hidden = torch.empty((M, H), device=dev, dtype=BF16)
         K.gather_rows(Xn, torch.tensor(inv, dtype=torch.int32, device=dev), hidden, M)
         keys = values = None
@@ -650,25 +603,19 @@ class MoTEngine:
         skw = self._get("skinny_ws_dec", (16 * B * max(2 * I, qkv_dim, V),), dtype=torch.float32)
         eps = d.rms_norm_eps
 
-        def lin(x, wt, out, **kw):
-            return K.skinny_gemm(x, wt, out, skw, **kw)
-
         steps_done = 0
         n_layers = len(w.layers)
+        # one argument block for every step: only the three table pointers move (tables of all steps were built above)
+        rows = K.mot_rows(0, B, X, Xn, QKV, Q, O, Hm, cos, sin, row_cs[0], row_slot[0], tiles[0], B, S, skw, und_rounding=True)
+        cs0, slot0, tile0 = row_cs.data_ptr(), row_slot.data_ptr(), tiles.data_ptr()
+        table = w.layer_table()
         for t in range(max_length):
             K.gather_rows(w.embed_tokens, seq[t], X, B)
-            K.rmsnorm(X, Xn, w.layers[0].ln_in[1], None, B, eps)
-            for l, lw in enumerate(w.layers):
-                lin(Xn, lw.wqkv[1], QKV, bias=lw.bqkv[1])
-                K.qk_norm_rope_kv(QKV, B, Hq, Hkv, D, lw.qn[1], None, lw.kn[1], None, B, cos, sin, row_cs[t], row_slot[t],
-                                  Q, kws[l], vtws[l], S, eps, und_rounding=True)
-                K.varlen_attention(Q, kws[l], vtws[l], O, tiles[t], B, Hq, Hkv, D, S)
-                # projection + residual + the RMSNorm that follows, one launch after the partial sums
-                K.skinny_gemm_residual_rmsnorm(O, lw.wo[1], X, X, lw.ln_post[1], Xn, eps, skw)
-                lin(Xn, lw.wgu[1], Hm, epilogue=K.SK_SWIGLU)
-                next_norm = w.layers[l + 1].ln_in[1] if l + 1 < n_layers else w.norm[1]
-                K.skinny_gemm_residual_rmsnorm(Hm, lw.wd[1], X, X, next_norm, Xn, eps, skw)
-            lin(Xn, w.lm_head, logits)
+            rows.row_cs, rows.row_slot, rows.tiles = cs0 + 4 * B * t, slot0 + 4 * B * t, tile0 + 32 * B * t
+            # 28 layers in one C call; with at most 64 rows every o_proj / down_proj reduces its partial sums, adds the
+            # residual and applies the RMSNorm that follows in one launch, the last one the model's final norm
+            K.mot_forward(self._cdims, table, n_layers, rows, kws, vtws, final_norm_und=w.norm[1])
+            K.skinny_gemm(Xn, w.lm_head, logits, skw)
             if logits_trace is not None:
                 logits_trace.append(logits.clone())
             if sample_fn is None:

@@ -213,14 +213,15 @@ def main():
         one_step()
     barrier()
     # per-launch timing of the dominant kernel with HIP events on the launch stream, during the timed region
-    model.engine.profile_events = []
+    from bagel_amd import _lib as K
+    K.profile_gate_up(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     barrier()
     elapsed = time.perf_counter() - t0
-    events = model.engine.profile_events
-    model.engine.profile_events = None
+    K.profile_gate_up(False)
+    events = K.profile_collect()            # (milliseconds, flops) per gate+up launch of the timed region
     ranks_info = {"world_size_seen": 1, "backend": None, "per_rank_ms_per_step": [elapsed / args.steps * 1e3],
                   "devices": [torch.cuda.get_device_name(dev)]}
     if world > 1:
@@ -250,9 +251,8 @@ def main():
         if events:
             # the dominant launch shape: all CFG branches packed (M = 3 x 4096 rows); the cond-only steps' smaller
             # launches of the same kernel are left out so that achieved, traffic and duration describe one shape
-            fmax = max(f for _, _, f in events)
-            events = [e for e in events if e[2] == fmax]
-            ms = [a.elapsed_time(b) for a, b, _ in events]
+            fmax = max(f for _, f in events)
+            ms = [m for m, f in events if f == fmax]
             flops = fmax
             avg = sum(ms) / len(ms)
             ach = flops / (avg * 1e-3) / 1e12

@@ -113,6 +113,66 @@ int bagel_layernorm_bf16(const void* x, long ldx, void* out, long ldo, int rows,
 int bagel_split_heads_pad_bf16(const void* qkv, long ld, int M, int heads, int head_dim_in, int head_dim,
                                const void* row_slot, void* Q, void* K_ws, void* Vt_ws, long S, void* stream);
 
+/* ---- one decoder layer / the whole layer stack as single calls ---------------------------------------------
+ * Qwen2MoTDecoderLayer.forward_inference (qwen2_navit.py:771-845) with PackedAttentionMoT.forward_inference
+ * (:510-611) inside, and the layer loop + final norm of Qwen2Model.forward_inference (:1079-1105).
+ * The packed sequence is sorted by expert: rows [0, rows_gen) use the generation expert, the following rows_und
+ * rows the understanding expert (mode="und": rows_gen == 0).  All pointers are device pointers; the weight layouts
+ * are those of bagel_gemm_bf16 / bagel_skinny_gemm_bf16 (wqkv = q|k|v rows fused, wgu = gate/up interleaved per 16
+ * features for BAGEL_EPI_SWIGLU); activations are row-contiguous bf16 at their natural widths. */
+typedef struct bagel_mot_dims {
+  int hidden, intermediate, num_heads, num_kv_heads, head_dim;
+  float rms_eps;
+} bagel_mot_dims;
+
+typedef struct bagel_mot_expert {      /* one expert's parameters of one layer */
+  const void *wqkv, *bqkv, *wo, *wgu, *wd; /* [(Hq+2Hkv)D, H], [(Hq+2Hkv)D], [H, Hq D], [2I, H], [H, I] */
+  const void *ln_in, *ln_post;             /* input_layernorm, post_attention_layernorm [H] */
+  const void *q_norm, *k_norm;             /* [D] */
+} bagel_mot_expert;
+
+typedef struct bagel_mot_layer {
+  bagel_mot_expert gen, und;           /* ``*_moe_gen`` parameters / plain parameters */
+} bagel_mot_layer;
+
+typedef struct bagel_mot_rows {        /* one packed forward: activations, tables, scratch */
+  int rows_gen, rows_und;
+  void *X, *Xn;                        /* [M][H] residual stream / normalised copy (M = rows_gen + rows_und) */
+  void *QKV, *Q, *O, *Hm;              /* [M][(Hq+2Hkv)D], [M][Hq D], [M][Hq D], [M][I] */
+  const void *cos_table, *sin_table;   /* RoPE rows, see bagel_qk_norm_rope_kv_bf16 */
+  const void *row_cs, *row_slot;       /* [M] int32 */
+  const void* tiles;                   /* attention tile table, see bagel_varlen_attention_bf16 */
+  int n_tiles;
+  long S;                              /* key slots per kv head in K_ws / Vt_ws */
+  void* skinny_ws;                     /* fp32 split-K partials: bagel_skinny_gemm_workspace_bytes(min(rows_und, 64), 2I) */
+  long skinny_ws_bytes;
+  int und_rounding;                    /* mode="und" rounding of the q/k norm and RoPE (qwen2_navit.py:526-530) */
+} bagel_mot_rows;
+
+#define BAGEL_LAYER_KV_ONLY 1  /* stop once the layer's keys/values are in K_ws / Vt_ws (last layer of a prefill) */
+#define BAGEL_LAYER_XN_READY 2 /* Xn already holds input_layernorm(X): the previous layer's call produced it */
+
+/* One layer, in place on r->X.  K_ws [Hkv][S][D] and Vt_ws [Hkv][D][S] are THIS layer's workspace slices.
+ * next_norm_gen / next_norm_und (optional): weights of the RMSNorm that follows the layer (the next layer's
+ * input_layernorm); when given, Xn holds that norm of the layer's output on return. */
+int bagel_mot_layer_forward(const bagel_mot_dims* dims, const bagel_mot_layer* layer, const bagel_mot_rows* rows,
+                            void* K_ws, void* Vt_ws, int flags, const void* next_norm_gen, const void* next_norm_und,
+                            void* stream);
+
+/* All layers: layer l uses K_ws + l * layer_stride and Vt_ws + l * layer_stride (elements).  kv_only_last != 0
+ * skips the last layer's attention and MLP (a context prefill only keeps keys/values).  Otherwise Xn holds
+ * norm(X) (final_norm_gen on the first rows_gen rows, final_norm_und on the rest; first final_norm_rows rows
+ * only when > 0) on return: Qwen2Model.norm / norm_moe_gen, qwen2_navit.py:1098-1105. */
+int bagel_mot_forward(const bagel_mot_dims* dims, const bagel_mot_layer* layers, int n_layers, const bagel_mot_rows* rows,
+                      void* K_ws, void* Vt_ws, long layer_stride, int kv_only_last, const void* final_norm_gen,
+                      const void* final_norm_und, int final_norm_rows, void* stream);
+
+/* Measurement hook (no counterpart in the reference): while on, every generation-expert gate+up GEMM launched by
+ * bagel_mot_layer_forward is bracketed by HIP events on its stream; bagel_profile_collect waits for them and
+ * returns (milliseconds, algorithmic flops) per launch. */
+void bagel_profile_gate_up(int on);
+int bagel_profile_collect(double* ms, double* flops, int cap);
+
 /* X[r] = bf16(bf16(lin[src_row[r]] + temb) + pos_table[pos_id[src_row[r]]]): bagel.py:1394-1399. */
 int bagel_embed_latent_bf16(const void* lin, long ldl, const void* temb, const void* pos_table, const void* pos_id,
                             const void* src_row, void* X, long ldx, int rows, int H, void* stream);
