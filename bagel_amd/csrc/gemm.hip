@@ -26,6 +26,10 @@
 #include "gemm_pipelined.h"
 #include <algorithm>
 
+#ifdef BAGEL_DIAG_CLOCK
+static unsigned long long* g_gemm_diag = nullptr;   // diagnostic builds: [2 x workgroups] stamps of the next launches
+extern "C" void bagel_set_gemm_diag(void* buf) { g_gemm_diag = (unsigned long long*)buf; }
+#endif
 static int g_gemm_variant = -1;  // -1: choose by problem size
 static int g_gemm_persistent = 1;  // 0: one workgroup per output tile
 
@@ -177,6 +181,10 @@ extern "C" int bagel_gemm_bf16(const void* A, long lda, const void* W, long ldw,
   p.bias = (const bf16*)bias;
   p.R = (const bf16*)residual; p.ldr = ldr;
   p.M = M; p.N = N; p.K = K; p.alpha = alpha;
+  p.diag = nullptr;
+#ifdef BAGEL_DIAG_CLOCK
+  p.diag = g_gemm_diag;
+#endif
   // 256-row software-pipelined tiles (8 waves, one workgroup per CU) or 128x128 tiles (4 waves, two
   // workgroups per CU).  Measured on the 7B gate+up shape (random operands): 128x128 1.10, 256x256
   // one-barrier loop 1.25, ping-pong 1.29, software-pipelined 1.38 PFLOP/s.

@@ -56,15 +56,20 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
     gemm_tile_of_block(p, t, tile_m, tile_n);
     m0 = tile_m * BM;
     n0 = tile_n * BN;
+#ifdef BAGEL_DIAG_SAME_TILE   // every workgroup loads tile (0, 0): what the kernel would do with no traffic beyond L2
+    const int lm0 = 0, ln0 = 0;
+#else
+    const int lm0 = m0, ln0 = n0;
+#endif
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = (it * NW + wave) * 8 + piece_row;
-      a_src[it] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + src_chunk * 8;
+      a_src[it] = p.A + (long)min(lm0 + row, p.M - 1) * p.lda + src_chunk * 8;
     }
 #pragma unroll
     for (int it = 0; it < W_ITERS; ++it) {
       const int row = (it * NW + wave) * 8 + piece_row;
-      w_src[it] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + src_chunk * 8;
+      w_src[it] = p.W + (long)min(ln0 + row, p.N - 1) * p.ldw + src_chunk * 8;
     }
   };
   auto stage_a_even = [&](int kt) {
@@ -193,6 +198,9 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
     }
   };
   int t = blockIdx.x;
+#ifdef BAGEL_DIAG_CLOCK   // shader cycles and 100 MHz reference ticks around the workgroup's whole life
+  const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   set_tile(t);
   stage_head();
   while (true) {
@@ -243,9 +251,26 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
       set_tile(tn);
       stage_head();
     }
+#ifdef BAGEL_DIAG_NO_EPILOGUE   // keeps the accumulators live, writes (almost) nothing
+    {
+      float keep = 0.f;
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (keep == 12345.678f) p.C[(long)out_m * p.ldc + out_n] = (bf16)keep;
+    }
+#else
     gemm_epilogue<EPI, FN, FM>(p, acc, out_m, out_n, lane);
+#endif
     if (tn >= ntiles) break;
     t = tn;
   }
+#ifdef BAGEL_DIAG_CLOCK
+  if (p.diag != nullptr && tid == 0) {
+    p.diag[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - diag_c0;
+    p.diag[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - diag_r0;
+  }
+#endif
 #endif
 }

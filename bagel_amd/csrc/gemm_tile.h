@@ -20,6 +20,7 @@ struct GemmParams {
   // 1 = the same on the 2x nearest-upsampled input; 2 = stride 2 with one zero row/column on the bottom/right.
   int Hout, Wout, Hin, Win, Cin, upsample;
   const bf16* zeros;
+  unsigned long long* diag;    // diagnostic builds only (BAGEL_DIAG_*): per-workgroup stamps; never read otherwise
 };
 
 constexpr int BK = 64;            // bf16 elements per K step (128-byte LDS rows)
@@ -46,65 +47,140 @@ __device__ __forceinline__ void gemm_tile_of_block(const GemmParams& p, int bloc
 
 // Epilogue shared by the tile kernels: this lane holds, for fragment (i, j), features
 // n_base + i*16 + fq*4 .. +3 of token row m_base + j*16 + frow  (fq = lane >> 4, frow = lane & 15).
+//
+// Two things keep it short (it runs with the matrix pipe idle, on every CU at the same moment):
+//  * Loads first, stores last.  The residual usually IS the output buffer (x += f(x)), so the compiler keeps every
+//    residual load behind every earlier store; fragment by fragment that is one exposed memory round trip per
+//    fragment.  All residual / bias values of a group of rows are requested before the group's first store.
+//  * 16-byte accesses.  A fragment gives a lane 4 features (8 bytes) and its 16-lane rows fq = 0..3 cover 32
+//    contiguous bytes of a token row.  One v_permlane16_swap per dword between the packed values of two
+//    neighbouring fragments X, Y leaves rows 0 / 2 with features 0-7 / 8-15 of X and rows 1 / 3 with those of Y,
+//    so each lane moves 16 contiguous bytes and a wave instruction covers 64-byte runs: half the memory
+//    instructions and requests for the same bytes.  The swap is its own inverse, so residual loads use it too.
+__device__ __forceinline__ void swap16(bf16x4& x, bf16x4& y) {
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+  union U { bf16x4 v; unsigned int d[2]; } a, b;
+  a.v = x;
+  b.v = y;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(a.d[k], b.d[k], false, false);
+    a.d[k] = r[0];
+    b.d[k] = r[1];
+  }
+  x = a.v;
+  y = b.v;
+}
+
 template <int EPI, int FN, int FM>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (&acc)[FN][FM], int m_base, int n_base,
                                               int lane) {
   const int frow = lane & 15, fq = lane >> 4;
+  constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_GELU;
+  constexpr bool HAS_RES = EPI == EPI_RESIDUAL || EPI == EPI_BIAS_RESIDUAL;
+  constexpr bool SWIGLU = EPI == EPI_SWIGLU;
+  constexpr int NV = SWIGLU ? FN / 2 : FN;      // packed 4-feature output values per row group
+  // Wide path: every column of this wave's tile is inside N and 16-byte accesses are aligned (uniform over the wave)
+  const int o_base = SWIGLU ? n_base / 2 : n_base;
+  bool wide = EPI != EPI_F32_SCALED && n_base + FN * 16 <= p.N && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 && o_base % 8 == 0;
+  if constexpr (HAS_RES) wide = wide && p.ldr % 8 == 0 && ((uintptr_t)p.R & 15) == 0;
+  // column of this lane's 16-byte access for the value pair (v, v + 1) / of its 8-byte access for value v
+  // (value v covers the 16 output features from o_base + 16 v: with SwiGLU a gate/up fragment pair makes one value)
+  auto wide_col = [&](int v) { return o_base + (v + (fq & 1)) * 16 + (fq >> 1) * 8; };
+  auto narrow_col = [&](int v) { return o_base + v * 16 + fq * 4; };
+
+  bf16x4 b4[FN];
+  if constexpr (HAS_BIAS) {
 #pragma unroll
-  for (int j = 0; j < FM; ++j) {
-    const int m = m_base + j * 16 + frow;
-    if (m >= p.M) continue;
-    if constexpr (EPI == EPI_SWIGLU) {
+    for (int i = 0; i < FN; ++i) {
+      const int n = n_base + i * 16 + fq * 4;
+      b4[i] = (p.bias != nullptr && n < p.N) ? *(const bf16x4*)(p.bias + n) : bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    }
+  }
+  constexpr int JG = HAS_RES ? (FM % 4 == 0 ? 4 : FM % 2 == 0 ? 2 : 1) : 1;   // row groups whose residuals are in flight together
 #pragma unroll
-      for (int i = 0; i < FN; i += 2) {
-        const int n = n_base + i * 16 + fq * 4;  // row of the interleaved weight
-        if (n >= p.N) continue;
-        const int f = (n_base + i * 16) / 2 + fq * 4;  // output feature
-        bf16x4 o;
+  for (int j0 = 0; j0 < FM; j0 += JG) {
+    bf16x4 r4[JG][FN];
+    if constexpr (HAS_RES) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float g = round_bf16(acc[i][j][r]);
-          const float u = round_bf16(acc[i + 1][j][r]);
-          o[r] = (bf16)(round_bf16(silu_f32(g)) * u);
+      for (int jj = 0; jj < JG; ++jj) {
+        const int m = min(m_base + (j0 + jj) * 16 + frow, p.M - 1);
+        const bf16* rrow = p.R + (long)m * p.ldr;
+        if (wide) {
+#pragma unroll
+          for (int i = 0; i + 1 < FN; i += 2) {
+            const bf16x8 w8 = *(const bf16x8*)(rrow + wide_col(i));
+            r4[jj][i] = bf16x4{w8[0], w8[1], w8[2], w8[3]};
+            r4[jj][i + 1] = bf16x4{w8[4], w8[5], w8[6], w8[7]};
+          }
+          if constexpr (FN % 2 == 1) r4[jj][FN - 1] = *(const bf16x4*)(rrow + narrow_col(FN - 1));
+        } else {
+#pragma unroll
+          for (int i = 0; i < FN; ++i) r4[jj][i] = *(const bf16x4*)(rrow + min(narrow_col(i), p.N - 4));
         }
-        *(bf16x4*)(p.C + (long)m * p.ldc + f) = o;
       }
-    } else {
+      if (wide) {
 #pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        const int n = n_base + i * 16 + fq * 4;
-        if (n >= p.N) continue;
-        bf16x4 o;
-        if constexpr (EPI == EPI_F32_SCALED) {
+        for (int jj = 0; jj < JG; ++jj)
+#pragma unroll
+          for (int i = 0; i + 1 < FN; i += 2) swap16(r4[jj][i], r4[jj][i + 1]);
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < JG; ++jj) {
+      const int j = j0 + jj;
+      const int m = m_base + j * 16 + frow;
+      if constexpr (EPI == EPI_F32_SCALED) {
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+          const int n = n_base + i * 16 + fq * 4;
+          if (n >= p.N) continue;
           f32x4 o32;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o32[r] = acc[i][j][r] * p.alpha;
           *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = o32;
-          continue;
-        } else if constexpr (EPI == EPI_RESIDUAL) {
-          const bf16x4 r4 = *(const bf16x4*)(p.R + (long)m * p.ldr + n);
+        }
+      } else {
+        // the packed output values of this 16-row group, then their stores
+        bf16x4 o[NV];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16)(round_bf16(acc[i][j][r]) + (float)r4[r]);
-        } else if constexpr (EPI == EPI_BIAS_RESIDUAL) {
-          const bf16x4 r4 = *(const bf16x4*)(p.R + (long)m * p.ldr + n);
-          const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
+        for (int v = 0; v < NV; ++v) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16)(round_bf16(acc[i][j][r] + (float)b4[r]) + (float)r4[r]);
-        } else if constexpr (EPI == EPI_BIAS_GELU) {
-          const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16)gelu_tanh_f32(round_bf16(acc[i][j][r] + (float)b4[r]));
-        } else {
-          if (p.bias != nullptr) {
-            const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (bf16)(acc[i][j][r] + (float)b4[r]);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (bf16)acc[i][j][r];
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (SWIGLU) {
+              const float g = round_bf16(acc[2 * v][j][r]);
+              const float u = round_bf16(acc[2 * v + 1][j][r]);
+              o[v][r] = (bf16)(round_bf16(silu_f32(g)) * u);
+            } else if constexpr (EPI == EPI_RESIDUAL) {
+              o[v][r] = (bf16)(round_bf16(acc[v][j][r]) + (float)r4[jj][v][r]);
+            } else if constexpr (EPI == EPI_BIAS_RESIDUAL) {
+              o[v][r] = (bf16)(round_bf16(acc[v][j][r] + (float)b4[v][r]) + (float)r4[jj][v][r]);
+            } else if constexpr (EPI == EPI_BIAS_GELU) {
+              o[v][r] = (bf16)gelu_tanh_f32(round_bf16(acc[v][j][r] + (float)b4[v][r]));
+            } else {
+              o[v][r] = (bf16)(acc[v][j][r] + (float)b4[v][r]);
+            }
           }
         }
-        *(bf16x4*)(p.C + (long)m * p.ldc + n) = o;
+        bf16* crow = p.C + (long)min(m, p.M - 1) * p.ldc;
+        if (wide) {   // the swaps need every lane, so rows past M take part and only skip their stores
+#pragma unroll
+          for (int v = 0; v + 1 < NV; v += 2) {
+            swap16(o[v], o[v + 1]);
+            if (m < p.M)
+              *(bf16x8*)(crow + wide_col(v)) = bf16x8{o[v][0], o[v][1], o[v][2], o[v][3], o[v + 1][0], o[v + 1][1], o[v + 1][2], o[v + 1][3]};
+          }
+          if constexpr (NV % 2 == 1) {
+            if (m < p.M) *(bf16x4*)(crow + narrow_col(NV - 1)) = o[NV - 1];
+          }
+        } else if (m < p.M) {
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            const int n_in = n_base + (SWIGLU ? 2 * v : v) * 16 + fq * 4;   // weight row that produced the value
+            if (n_in < p.N) *(bf16x4*)(crow + narrow_col(v)) = o[v];
+          }
+        }
       }
     }
   }

@@ -36,6 +36,7 @@ extern "C" int bagel_conv3x3_nhwc_bf16(const void* x, int Hin, int Win, int Cin,
   p.M = p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin;
   p.alpha = 1.f;
   p.zeros = (const bf16*)zero_page;
+  p.diag = nullptr;
   constexpr int BM = 128, BN = 128;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
