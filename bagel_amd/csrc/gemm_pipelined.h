@@ -198,6 +198,11 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
     }
   };
   int t = blockIdx.x;
+  // true when the previous tile's epilogue left exactly EPI_STORES store instructions in flight behind this tile's
+  // first DMA pieces: the wait below then covers the DMA alone and the stores drain under the first K step
+  bool stores_behind = false;
+  constexpr int EPI_STORES = gemm_epilogue_wide_stores<EPI, FN, FM>();
+  static_assert(EPI_STORES <= 63, "s_waitcnt vmcnt holds 6 bits");
 #ifdef BAGEL_DIAG_CLOCK   // shader cycles and 100 MHz reference ticks around the workgroup's whole life
   const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -208,8 +213,11 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
     for (int i = 0; i < FN; ++i)
 #pragma unroll
       for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // K tiles 0 and 1 were issued before the previous tile's epilogue (or just above): publish tile 0
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // K tiles 0 and 1 were issued before the previous tile's epilogue (or just above): publish tile 0.
+    // vmcnt counts loads, LDS-DMA and stores together in issue order, so "all but the EPI_STORES youngest" is
+    // exactly "every DMA piece has landed" when the epilogue issued that many stores after them.
+    if (stores_behind) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(EPI_STORES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     read_a(smem, 0, 0, 0);
     read_w(smem, 0);
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
       if (keep == 12345.678f) p.C[(long)out_m * p.ldc + out_n] = (bf16)keep;
     }
 #else
-    gemm_epilogue<EPI, FN, FM>(p, acc, out_m, out_n, lane);
+    stores_behind = gemm_epilogue<EPI, FN, FM>(p, acc, out_m, out_n, lane);
 #endif
     if (tn >= ntiles) break;
     t = tn;

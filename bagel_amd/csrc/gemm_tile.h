@@ -72,8 +72,18 @@ __device__ __forceinline__ void swap16(bf16x4& x, bf16x4& y) {
   y = b.v;
 }
 
+// Store instructions the wide path issues per wave when no row or column of the wave's tile is cut off.
 template <int EPI, int FN, int FM>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (&acc)[FN][FM], int m_base, int n_base,
+constexpr int gemm_epilogue_wide_stores() {
+  constexpr int NV = EPI == EPI_SWIGLU ? FN / 2 : FN;
+  return FM * (NV / 2 + NV % 2);
+}
+
+// Returns true (uniform over the wave) when exactly gemm_epilogue_wide_stores() store instructions were issued, all
+// of them after every load of this function: a caller with older asynchronous loads in flight may then wait with
+// s_waitcnt vmcnt(that count) for its loads alone and let the stores drain under later work.
+template <int EPI, int FN, int FM>
+__device__ __forceinline__ bool gemm_epilogue(const GemmParams& p, const f32x4 (&acc)[FN][FM], int m_base, int n_base,
                                               int lane) {
   const int frow = lane & 15, fq = lane >> 4;
   constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_GELU;
@@ -184,6 +194,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
       }
     }
   }
+  return wide && m_base + FM * 16 <= p.M;
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, int AMODE>
