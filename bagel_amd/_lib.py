@@ -183,6 +183,18 @@ def skinny_gemm_residual_rmsnorm(X, W, C, residual, norm_weight, Xn, eps, worksp
     return C
 
 
+def skinny_gemm_rmsnorm_in(X, norm_weight, eps, W, C, workspace, Xn=None, bias=None, epilogue=SK_BIAS):
+    """C = epilogue(RMSNorm(X) @ W^T) for at most 64 rows; Xn: scratch rows for shapes the fused kernel does not take."""
+    M, K = X.shape
+    N = W.shape[0]
+    _check(lib().bagel_skinny_gemm_rmsnorm_in_bf16(_p(X), L(X.stride(0)), _p(norm_weight), F(eps), _p(W), L(W.stride(0)), _p(C),
+                                                   L(C.stride(0)), I(M), I(N), I(K), _p(bias), I(epilogue), _p(Xn),
+                                                   L(Xn.stride(0) if Xn is not None else 0), _p(workspace),
+                                                   L(workspace.numel() * workspace.element_size()), _stream()),
+           "bagel_skinny_gemm_rmsnorm_in_bf16")
+    return C
+
+
 def rmsnorm(x, out, w_first, w_second, split_row, eps, rows=None):
     rows = x.shape[0] if rows is None else rows
     _check(lib().bagel_rmsnorm_bf16(_p(x), L(x.stride(0)), _p(out), L(out.stride(0)), I(rows), I(x.shape[1]),

@@ -91,6 +91,26 @@ extern "C" int bagel_mot_layer_forward(const bagel_mot_dims* d, const bagel_mot_
   void* X_u = at(r->X, Mv, H);
   void* Xn_u = at(r->Xn, Mv, H);
 
+  if (flags & BAGEL_LAYER_NORM_IN_GEMM) {
+    // understanding rows only, a handful of them (a decode step): both RMSNorms are applied inside the
+    // weight-streaming kernels that consume them, so the layer is seven launches and Xn is never written
+    BAGEL_CHECK(Mv == 0 && Mt <= 64, "bagel_mot_layer_forward: BAGEL_LAYER_NORM_IN_GEMM needs rows_gen == 0 and rows_und <= 64");
+    TRY(bagel_skinny_gemm_rmsnorm_in_bf16(r->X, H, u.ln_in, eps, u.wqkv, H, r->QKV, qkv, Mt, qkv, H, u.bqkv, BAGEL_SK_BIAS, r->Xn,
+                                          H, r->skinny_ws, r->skinny_ws_bytes, stream));
+    TRY(bagel_qk_norm_rope_kv_bf16(r->QKV, qkv, M, Hq, Hkv, D, u.q_norm, u.q_norm, u.k_norm, u.k_norm, M, r->cos_table,
+                                   r->sin_table, r->row_cs, r->row_slot, r->Q, K_ws, Vt_ws, r->S, eps, r->und_rounding, stream));
+    if (flags & BAGEL_LAYER_KV_ONLY) return 0;
+    BAGEL_CHECK(r->O && r->Hm && r->tiles && r->n_tiles > 0, "bagel_mot_layer_forward: null attention / MLP buffer");
+    TRY(bagel_varlen_attention_bf16(r->Q, K_ws, Vt_ws, r->O, r->tiles, r->n_tiles, Hq, Hkv, D, r->S, stream));
+    TRY(bagel_skinny_gemm_bf16(r->O, qd, u.wo, qd, r->X, H, Mt, H, qd, nullptr, r->X, H, BAGEL_SK_RESIDUAL, r->skinny_ws,
+                               r->skinny_ws_bytes, stream));
+    TRY(bagel_skinny_gemm_rmsnorm_in_bf16(r->X, H, u.ln_post, eps, u.wgu, H, r->Hm, I, Mt, 2 * I, H, nullptr, BAGEL_SK_SWIGLU,
+                                          r->Xn, H, r->skinny_ws, r->skinny_ws_bytes, stream));
+    TRY(bagel_skinny_gemm_bf16(r->Hm, I, u.wd, I, r->X, H, Mt, H, I, nullptr, r->X, H, BAGEL_SK_RESIDUAL, r->skinny_ws,
+                               r->skinny_ws_bytes, stream));
+    if (next_norm_und) TRY(bagel_rmsnorm_bf16(r->X, H, r->Xn, H, M, H, next_norm_und, next_norm_und, M, eps, stream));
+    return 0;
+  }
   if (!(flags & BAGEL_LAYER_XN_READY)) TRY(bagel_rmsnorm_bf16(r->X, H, r->Xn, H, M, H, ln_in_a, u.ln_in, split, eps, stream));
   if (Mv) TRY(bagel_gemm_bf16(r->Xn, H, g.wqkv, H, r->QKV, qkv, Mv, qkv, H, g.bqkv, nullptr, 0, BAGEL_EPI_BIAS, 1.0f, stream));
   if (Mt) TRY(und_linear(Xn_u, H, u.wqkv, at(r->QKV, Mv, qkv), qkv, Mt, qkv, H, u.bqkv, nullptr, 0, 0, r, stream));
@@ -141,6 +161,20 @@ extern "C" int bagel_mot_forward(const bagel_mot_dims* d, const bagel_mot_layer*
                                  const void* final_norm_gen, const void* final_norm_und, int final_norm_rows, void* stream) {
   BAGEL_CHECK(d && layers && r && n_layers > 0 && layer_stride > 0, "bagel_mot_forward: bad argument");
   const int Mv = r->rows_gen;
+  // a decode step (up to four understanding rows, nothing else): the norms move into the weight-streaming kernels
+  const bool lazy_norm = Mv == 0 && r->rows_und <= 4 &&
+                         bagel_skinny_gemv_eligible(r->rows_und, (d->num_heads + 2 * d->num_kv_heads) * d->head_dim, d->hidden, BAGEL_SK_BIAS);
+  if (lazy_norm) {
+    for (int l = 0; l < n_layers; ++l) {
+      const bool last = l + 1 == n_layers;
+      const int flags = BAGEL_LAYER_NORM_IN_GEMM | (last && kv_only_last ? BAGEL_LAYER_KV_ONLY : 0);
+      // Xn is only produced where the caller asked for the final norm
+      const void* nu = last && !kv_only_last ? final_norm_und : nullptr;
+      TRY(bagel_mot_layer_forward(d, &layers[l], r, (char*)K_ws + (long)l * layer_stride * 2,
+                                  (char*)Vt_ws + (long)l * layer_stride * 2, flags, nullptr, nu, stream));
+    }
+    return 0;
+  }
   for (int l = 0; l < n_layers; ++l) {
     const bool last = l + 1 == n_layers;
     int flags = l > 0 ? BAGEL_LAYER_XN_READY : 0;     // every layer leaves the next one's input norm in Xn

@@ -150,6 +150,185 @@ __global__ __launch_bounds__(RN_THREADS) void skinny_reduce_rmsnorm_kernel(const
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// At most 4 token rows (a decode step of up to four samples, the two text tokens of up to two units): a GEMV-shaped kernel with no
+// split-K and no partial sums.  A wave owns NF weight rows over the WHOLE reduction; its 64 lanes split K in
+// 16-byte pieces, so every load instruction reads 1 KiB that is contiguous in memory (the weight row itself),
+// up to three steps in flight behind the one being multiplied.  v_dot2c_f32_bf16 accumulates in fp32 per lane; the lanes'
+// sums are combined by a butterfly that halves the number of live values at every exchange, after which lane 4 v
+// holds output value v.  Bias / SiLU / residual / SwiGLU are applied there, so one launch replaces the
+// partial-sum and reduce launches of the split-K form and writes no fp32 intermediates.
+// Values are numbered v = m * NF + f (row m, weight row f of the wave).  With SwiGLU the wave's NF weight rows
+// are NF/2 (gate, up) pairs: rows f and f + 16 of the [16 gate | 16 up] interleave.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+// NORM: the rows of X are RMS-normalised on the way in (Qwen2RMSNorm, modeling_qwen2.py:54-59: x_n = w * bf16(x * rs),
+// rs = rsqrt(mean(x^2) + eps)), with the same lane / element assignment and summation order as rmsnorm_kernel.  Every
+// wave recomputes the few rows' statistics from L1 / L2 (K * 2 bytes per row), which costs less than the launch and
+// the round trip of a separate normalisation kernel.
+template <int NF, int MR, int ST, bool NORM>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const bf16* __restrict__ X, long ldx, const bf16* __restrict__ W,
+                                                        long ldw, bf16* __restrict__ C, long ldc, int M, int N, int K,
+                                                        const bf16* __restrict__ bias, const bf16* __restrict__ R,
+                                                        long ldr, int epilogue, const bf16* __restrict__ norm_w,
+                                                        float eps) {
+  constexpr int V = NF * MR;              // values per wave, a power of two <= 32
+  static_assert((V & (V - 1)) == 0 && V <= 32, "NF * MR must be a power of two, at most 32");
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool swiglu = epilogue == SK_SWIGLU;
+  // weight rows of this wave
+  int wrow[NF];
+  if (swiglu) {
+    // pair p of the wave covers output feature o = wave * (NF / 2) + p: gate row (o / 16) * 32 + o % 16, up row + 16
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int o = wave * (NF / 2) + (f >> 1);
+      wrow[f] = (o >> 4) * 32 + (o & 15) + (f & 1) * 16;
+    }
+  } else {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) wrow[f] = wave * NF + f;
+  }
+  if (wrow[0] >= N) return;               // whole wave out of range (N is a multiple of NF / of 32 with SwiGLU)
+  const bf16* wp[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) wp[f] = W + (long)min(wrow[f], N - 1) * ldw + lane * 8;
+  const bf16* xp[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) xp[m] = X + (long)min(m, M - 1) * ldx + lane * 8;
+
+  float acc[MR][NF];
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int f = 0; f < NF; ++f) acc[m][f] = 0.f;
+
+  const int nsteps = K / 512;             // K % 512 == 0 is checked by the launcher
+  float rs[MR];
+  if constexpr (NORM) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      float ss = 0.f;
+      for (int step = 0; step < nsteps; ++step) {
+        const bf16x8 v = *(const bf16x8*)(xp[m] + step * 512);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += (float)v[j] * (float)v[j];
+      }
+      rs[m] = rsqrtf(wave_sum(ss) / (float)K + eps);
+    }
+  }
+  // ST register stages: the loads of the next ST - 1 steps are in flight behind the step being multiplied
+  bf16x8 wf[ST][NF], xf[ST][MR], nf[ST];
+  auto load = [&](int st, int step) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) wf[st][f] = *(const bf16x8*)(wp[f] + step * 512);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) xf[st][m] = *(const bf16x8*)(xp[m] + step * 512);
+    if constexpr (NORM) nf[st] = *(const bf16x8*)(norm_w + lane * 8 + step * 512);
+  };
+  auto compute = [&](int st) {
+    if constexpr (NORM) {
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[st][m][j] = (bf16)((float)nf[st][j] * round_bf16((float)xf[st][m][j] * rs[m]));
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[m][f] = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{wf[st][f][2 * e], wf[st][f][2 * e + 1]},
+                                                      bf16x2_t{xf[st][m][2 * e], xf[st][m][2 * e + 1]}, acc[m][f], false);
+  };
+#pragma unroll
+  for (int j = 0; j < ST - 1; ++j)
+    if (j < nsteps) load(j, j);
+  for (int step = 0; step < nsteps; step += ST) {
+#pragma unroll
+    for (int j = 0; j < ST; ++j) {
+      if (step + j + ST - 1 < nsteps) load((j + ST - 1) % ST, step + j + ST - 1);
+      if (step + j < nsteps) compute(j);
+    }
+  }
+
+  // butterfly: after the exchange with lane ^ 32 a lane keeps the values whose top index bit equals its own bit 5,
+  // and so on down to one value per group of (64 / V) lanes, which the last exchanges sum completely
+  float val[V];
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int f = 0; f < NF; ++f) val[m * NF + f] = acc[m][f];
+  int width = 32;
+#pragma unroll
+  for (int n = V; n > 1; n >>= 1, width >>= 1) {
+    const bool upper = (lane & width) != 0;
+#pragma unroll
+    for (int i = 0; i < n / 2; ++i) {
+      const float keep = upper ? val[i + n / 2] : val[i];
+      const float give = upper ? val[i] : val[i + n / 2];
+      val[i] = keep + __shfl_xor(give, width, 64);
+    }
+  }
+  float total = val[0];
+#pragma unroll
+  for (; width >= 1; width >>= 1) total += __shfl_xor(total, width, 64);
+  // every lane of a group of 64 / V lanes now holds the total of value v = lane / (64 / V)
+  constexpr int GROUP = 64 / V;
+  const int v = lane / GROUP, m = v / NF, f = v % NF;
+  float partner = 0.f;
+  if (swiglu) partner = __shfl_xor(total, GROUP, 64);      // gate lanes (f even) receive the up value of their pair
+  if ((lane % GROUP) != 0 || m >= M) return;
+  if (swiglu) {
+    if (f & 1) return;
+    const int o = wave * (NF / 2) + (f >> 1);
+    const float g = round_bf16(total), u = round_bf16(partner);
+    C[(long)m * ldc + o] = (bf16)(round_bf16(silu_f32(g)) * u);
+    return;
+  }
+  const int n = wrow[0] + f;
+  if (n >= N) return;
+  float a = total;
+  if (bias) a += (float)bias[n];
+  if (epilogue == SK_RESIDUAL) a = round_bf16(a) + (float)R[(long)m * ldr + n];
+  if (epilogue == SK_BIAS_SILU) a = silu_f32(round_bf16(a));
+  C[(long)m * ldc + n] = (bf16)a;
+}
+
+static bool gemv_eligible(int M, int N, int K, int epilogue) {
+  if (K % 512 != 0 || N % 4 != 0 || (epilogue == SK_SWIGLU && N % 32 != 0)) return false;
+  // measured on MI355X against the split-K form (tools/skinny_bench.py): ahead at one or two rows for every shape
+  // (15 % per layer), at three or four rows only for the narrow projections
+  return M <= 2 || (M <= 4 && epilogue != SK_SWIGLU && N <= 16384);
+}
+
+static int g_skinny_gemv = 1;   // development knob: 0 forces the split-K form (bagel_set_skinny_gemv)
+extern "C" void bagel_set_skinny_gemv(int on) { g_skinny_gemv = on; }
+
+static void gemv_launch(const bf16* X, long ldx, const bf16* W, long ldw, bf16* C, long ldc, int M, int N, int K,
+                        const bf16* bias, const bf16* R, long ldr, int epilogue, const bf16* norm_w, float eps,
+                        hipStream_t st) {
+  // NF weight rows per wave: enough of them that the activation rows (re-read by every wave, from L1 / L2) stay a
+  // small multiple of the weight bytes on the load path
+#define GEMV(NF, MR, ST, NORM)                                                                                        \
+  hipLaunchKernelGGL((gemv_rows_kernel<NF, MR, ST, NORM>), dim3((N / NF + 3) / 4), dim3(256), 0, st, X, ldx, W, ldw, C,   \
+                     ldc, M, N, K, bias, R, ldr, epilogue, norm_w, eps)
+  // (one weight row per wave, i.e. twice the waves, measured no faster on the narrow projections)
+  if (norm_w) {
+    if (M <= 1) GEMV(2, 1, 4, true);
+    else if (M <= 2) GEMV(2, 2, 4, true);
+    else GEMV(2, 4, 2, true);
+  } else {
+    if (M <= 1) GEMV(2, 1, 4, false);
+    else if (M <= 2) GEMV(2, 2, 4, false);
+    else GEMV(2, 4, 2, false);
+  }
+#undef GEMV
+}
+
 extern "C" long bagel_skinny_gemm_workspace_bytes(int M, int N) { return (long)16 * M * N * sizeof(float); }
 
 static int skinny_launch(const void* X, long ldx, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
@@ -165,6 +344,12 @@ static int skinny_launch(const void* X, long ldx, const void* W, long ldw, void*
   if (epilogue == SK_RESIDUAL) BAGEL_CHECK(residual, "bagel_skinny_gemm_bf16: residual epilogue needs R");
   if (epilogue == SK_SWIGLU) BAGEL_CHECK(N % 32 == 0, "bagel_skinny_gemm_bf16: swiglu needs N %% 32 == 0");
   if (norm_weight) BAGEL_CHECK(Xn && epilogue == SK_RESIDUAL && N <= RN_THREADS * RN_MAXC, "bagel_skinny_gemm_residual_rmsnorm_bf16: bad arguments");
+  if (g_skinny_gemv && !norm_weight && gemv_eligible(M, N, K, epilogue)) {
+    gemv_launch((const bf16*)X, ldx, (const bf16*)W, ldw, (bf16*)C, ldc, M, N, K, (const bf16*)bias, (const bf16*)residual, ldr,
+                epilogue, nullptr, 0.f, (hipStream_t)stream);
+    BAGEL_LAUNCH_CHECK();
+    return 0;
+  }
   // K slices (at most 16, at least two 128-deep steps each) so that the grid has about 24 waves per CU: the
   // kernel is latency-bound per wave, and HBM only saturates with tens of KB in flight per CU
   const int ksteps = K / 128, ngroups = N / 16;
@@ -204,6 +389,35 @@ extern "C" int bagel_skinny_gemm_bf16(const void* X, long ldx, const void* W, lo
                                       int epilogue, void* workspace, long workspace_bytes, void* stream) {
   return skinny_launch(X, ldx, W, ldw, C, ldc, M, N, K, bias, residual, ldr, epilogue, workspace, workspace_bytes, nullptr,
                        nullptr, 0, 0.f, stream);
+}
+
+extern "C" int bagel_skinny_gemv_eligible(int M, int N, int K, int epilogue) {
+  return g_skinny_gemv && gemv_eligible(M, N, K, epilogue) ? 1 : 0;
+}
+
+extern "C" int bagel_rmsnorm_bf16(const void* x, long ldx, void* out, long ldo, int rows, int H, const void* w_first,
+                                  const void* w_second, int split_row, float eps, void* stream);
+
+extern "C" int bagel_skinny_gemm_rmsnorm_in_bf16(const void* X, long ldx, const void* norm_weight, float eps, const void* W,
+                                                 long ldw, void* C, long ldc, int M, int N, int K, const void* bias,
+                                                 int epilogue, void* Xn, long ldn, void* workspace, long workspace_bytes,
+                                                 void* stream) {
+  BAGEL_CHECK(X && W && C && norm_weight, "bagel_skinny_gemm_rmsnorm_in_bf16: null operand");
+  BAGEL_CHECK(M > 0 && M <= 64, "bagel_skinny_gemm_rmsnorm_in_bf16: M=%d outside 1..64", M);
+  BAGEL_CHECK(epilogue == SK_BIAS || epilogue == SK_SWIGLU || epilogue == SK_BIAS_SILU,
+              "bagel_skinny_gemm_rmsnorm_in_bf16: epilogue %d takes no normalised input", epilogue);
+  BAGEL_CHECK(ldx % 8 == 0 && ldw % 8 == 0 && ldx >= K && ldw >= K && K % 8 == 0, "bagel_skinny_gemm_rmsnorm_in_bf16: bad leading dims");
+  BAGEL_CHECK(((uintptr_t)X | (uintptr_t)W | (uintptr_t)norm_weight) % 16 == 0, "bagel_skinny_gemm_rmsnorm_in_bf16: misaligned operand");
+  if (g_skinny_gemv && N > 0 && gemv_eligible(M, N, K, epilogue)) {
+    gemv_launch((const bf16*)X, ldx, (const bf16*)W, ldw, (bf16*)C, ldc, M, N, K, (const bf16*)bias, nullptr, 0, epilogue,
+                (const bf16*)norm_weight, eps, (hipStream_t)stream);
+    BAGEL_LAUNCH_CHECK();
+    return 0;
+  }
+  BAGEL_CHECK(Xn && ldn >= K && ldn % 8 == 0, "bagel_skinny_gemm_rmsnorm_in_bf16: this shape needs the Xn scratch rows");
+  if (int rc = bagel_rmsnorm_bf16(X, ldx, Xn, ldn, M, K, norm_weight, norm_weight, M, eps, stream)) return rc;
+  return skinny_launch(Xn, ldn, W, ldw, C, ldc, M, N, K, bias, nullptr, 0, epilogue, workspace, workspace_bytes, nullptr, nullptr,
+                       0, 0.f, stream);
 }
 
 extern "C" int bagel_skinny_gemm_residual_rmsnorm_bf16(const void* X, long ldx, const void* W, long ldw, void* C, long ldc,

@@ -612,10 +612,12 @@ class MoTEngine:
         for t in range(max_length):
             K.gather_rows(w.embed_tokens, seq[t], X, B)
             rows.row_cs, rows.row_slot, rows.tiles = cs0 + 4 * B * t, slot0 + 4 * B * t, tile0 + 32 * B * t
-            # 28 layers in one C call; with at most 64 rows every o_proj / down_proj reduces its partial sums, adds the
-            # residual and applies the RMSNorm that follows in one launch, the last one the model's final norm
-            K.mot_forward(self._cdims, table, n_layers, rows, kws, vtws, final_norm_und=w.norm[1])
-            K.skinny_gemm(Xn, w.lm_head, logits, skw)
+            # 28 layers in one C call.  Up to four samples: seven launches per layer, the RMSNorms run inside the
+            # weight-streaming kernels that consume them; more: o_proj / down_proj reduce their partial sums, add the
+            # residual and apply the RMSNorm that follows in one launch
+            K.mot_forward(self._cdims, table, n_layers, rows, kws, vtws)
+            # final norm + lm_head in one weight-streaming launch
+            K.skinny_gemm_rmsnorm_in(X, w.norm[1], eps, w.lm_head, logits, skw, Xn=Xn)
             if logits_trace is not None:
                 logits_trace.append(logits.clone())
             if sample_fn is None:

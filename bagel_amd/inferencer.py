@@ -76,18 +76,27 @@ class CfgContexts:
         self.full = inferencer.init_gen_context()
         self.no_text = self.full.fork()
         self.no_image = self.full.fork()
+        # Until the request's first image, ``no_image`` has received exactly what ``full`` has: it is then kept as a
+        # fork of ``full`` (same tensors) instead of being prefilled a second time with the same tokens.
+        self._text_only = True
+
+    def _text_to_both(self, text: str):
+        self._inf.update_context_text(text, self.full)
+        if self._text_only:
+            self.no_image = self.full.fork()
+        else:
+            self._inf.update_context_text(text, self.no_image)
 
     def add_system_prompt(self, prompt: str):
         # a system prompt is part of both the conditional and the image-free context, never of the text-free one
-        self._inf.update_context_text(prompt, self.full)
-        self._inf.update_context_text(prompt, self.no_image)
+        self._text_to_both(prompt)
 
     def add_text(self, text: str):
         self.no_text = self.full.fork()                      # everything up to, but not including, this text
-        self._inf.update_context_text(text, self.full)
-        self._inf.update_context_text(text, self.no_image)
+        self._text_to_both(text)
 
     def add_image(self, image, with_vae_tokens: bool):
+        self._text_only = False
         self._inf.update_context_image(image, self.full, vae=with_vae_tokens)
         self.no_text = self.full.fork()                      # images stay in the text-free context
 
@@ -100,6 +109,8 @@ class InterleaveInferencer:
         self.vae_transform = vae_transform
         self.vit_transform = vit_transform
         self.new_token_ids = new_token_ids
+        # opt-in (not in the reference): skip CFG branches that were given the conditional branch's own context
+        self.dedup_identical_branches = False
 
     # ---- contexts ---------------------------------------------------------------------------------------
     def init_gen_context(self) -> GenContext:
@@ -157,7 +168,8 @@ class InterleaveInferencer:
         latents = model.generate_image(num_timesteps=num_timesteps, timestep_shift=timestep_shift,
                                        cfg_text_scale=cfg_text_scale, cfg_img_scale=cfg_img_scale, cfg_interval=cfg_interval,
                                        cfg_renorm_min=cfg_renorm_min, cfg_renorm_type=cfg_renorm_type,
-                                       enable_taylorseer=enable_taylorseer, **kwargs)
+                                       enable_taylorseer=enable_taylorseer,
+                                       dedup_identical_branches=self.dedup_identical_branches, **kwargs)
         return self.decode_image(latents[0], image_shape)
 
     def decode_image(self, latent, image_shape):

@@ -314,6 +314,17 @@ class Bagel:
             raise NotImplementedError("packed_text_indexes / packed_vae_token_indexes do not follow the "
                                       "[start_of_image, latent tokens, end_of_image] layout of prepare_vae_latent")
 
+    @staticmethod
+    def _same_unit(a: GenUnit, b: GenUnit) -> bool:
+        """Two units compute the same thing when they serve the same sample at the same RoPE position over the SAME
+        context tensors (same storage and extent in every layer: no data is compared)."""
+        if (a.sample, a.ctx_len, a.rope_pos) != (b.sample, b.ctx_len, b.rope_pos):
+            return False
+        if a.ctx_len == 0:
+            return True
+        same = lambda x, y: x.data_ptr() == y.data_ptr() and x.shape == y.shape and x.stride() == y.stride()  # noqa: E731
+        return all(same(x, y) for x, y in zip(a.ctx_k, b.ctx_k)) and all(same(x, y) for x, y in zip(a.ctx_v, b.ctx_v))
+
     def _branch_units(self, branch: int, seqlens: List[int], position_ids, query_indexes, past: Optional[NaiveCache],
                       kv_lens, kv_indexes) -> List[GenUnit]:
         """Per-sample units of one CFG branch from the reference's packed description of that branch
@@ -391,6 +402,7 @@ class Bagel:
         trace: Optional[list] = None,
         teacher_x: Optional[Sequence[torch.Tensor]] = None,
         group=None,
+        dedup_identical_branches: bool = False,
     ):
         """Bagel.generate_image (bagel.py:1237-1347).  Returns a tuple of per-image ``[Nv, 64]`` fp32 latents
         (on the device).  ``enable_taylorseer`` skips two of three forwards after the first five steps and
@@ -398,7 +410,11 @@ class Bagel:
         CFG branches start at step 0, so that their schedules coincide and the packed forward stays one launch.
         When torch.distributed is initialised with more than one rank, the (sample, branch) units of each
         step are split over the ranks of ``group`` (bagel_amd/parallel.py); every rank must make the same call
-        and every rank returns the same latents."""
+        and every rank returns the same latents.
+        ``dedup_identical_branches`` (not in the reference, off by default): when the image-free CFG branch is given
+        exactly the conditional branch's context for every sample - what text-to-image requests do
+        (inferencer.py:283-285) - its forward is bit-identical to the conditional one, so it is not run and the
+        conditional velocity is used for it; results do not change, a third of every CFG step's work goes away."""
         if cfg_renorm_type not in K.RENORM and cfg_text_scale > 1.0:
             raise NotImplementedError(f"{cfg_renorm_type} is not suppoprted")
         eng, d, dev = self.engine, self.dims, self.device
@@ -418,14 +434,18 @@ class Bagel:
             units += self._branch_units(1, seqlens, cpu(cfg_text_packed_position_ids), cpu(cfg_text_packed_query_indexes),
                                         cfg_text_past_key_values, cpu(cfg_text_key_values_lens),
                                         cpu(cfg_text_packed_key_value_indexes))
+        img_is_cond = False
         if use_img:
-            units += self._branch_units(2, seqlens, cpu(cfg_img_packed_position_ids), cpu(cfg_img_packed_query_indexes),
-                                        cfg_img_past_key_values, cpu(cfg_img_key_values_lens),
-                                        cpu(cfg_img_packed_key_value_indexes))
+            img_units = self._branch_units(2, seqlens, cpu(cfg_img_packed_position_ids), cpu(cfg_img_packed_query_indexes),
+                                           cfg_img_past_key_values, cpu(cfg_img_key_values_lens),
+                                           cpu(cfg_img_packed_key_value_indexes))
+            img_is_cond = dedup_identical_branches and all(self._same_unit(a, b) for a, b in zip(units[:n_cond], img_units))
+            if not img_is_cond:
+                units += img_units
 
         # split the units over the ranks (one process per GPU); world == 1 keeps everything local
         rank, world = world_info(group)
-        n_br = 1 + int(use_text) + int(use_img)
+        n_br = 1 + int(use_text) + int(use_img and not img_is_cond)
         ex_full = plan_exchange([u.sample for u in units], [u.branch for u in units], sample_nv, n_br, rank, world)
         ex_cond = plan_exchange([u.sample for u in units[:n_cond]], [0] * n_cond, sample_nv, n_br, rank, world)
         local_full = [units[i] for i in ex_full.local_units]
@@ -484,7 +504,7 @@ class Bagel:
             plan, ex = (plan_full, ex_full) if full else (plan_cond, ex_cond)
             tstep = None
             if schedules is not None:
-                active_br = [0] + ([1] if full else []) + ([2] if (full and use_img) else [])
+                active_br = [0] + ([1] if full else []) + ([2] if (full and use_img and not img_is_cond) else [])
                 kinds = {schedules[b].advance() for b in active_br}
                 counts = {schedules[b].n_factors for b in active_br}
                 if len(kinds) != 1 or len(counts) != 1:
@@ -500,7 +520,7 @@ class Bagel:
             vout = exchange_velocities(vloc, ex, d.patch_latent_dim, dev, BF16, group)
             v_cond = vout[:Nv]
             v_text = vout[Nv:2 * Nv] if full else None
-            v_img = vout[2 * Nv:3 * Nv] if (full and use_img) else None
+            v_img = (v_cond if img_is_cond else vout[2 * Nv:3 * Nv]) if (full and use_img) else None
             if trace is not None:
                 rec = {"x_t": x_t.clone(), "v_cond": v_cond.clone()}
                 if v_text is not None:

@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--taylorseer", action="store_true",
                     help="enable_taylorseer=True (two of three forwards skipped after step 4): a different workload, "
                          "not the headline configuration")
+    ap.add_argument("--dedup-identical-branches", action="store_true",
+                    help="skip the image-free CFG branch where it has the conditional branch's context (always, in "
+                         "text-to-image): same results, a different amount of work - not the headline configuration")
     return ap.parse_args()
 
 
@@ -174,7 +177,8 @@ def main():
             cfg_img_packed_position_ids=gm["cfg_packed_position_ids"],
             cfg_img_packed_query_indexes=gm["cfg_packed_query_indexes"],
             cfg_img_key_values_lens=gm["cfg_key_values_lens"],
-            cfg_img_packed_key_value_indexes=gm["cfg_packed_key_value_indexes"], enable_taylorseer=args.taylorseer, **gi)
+            cfg_img_packed_key_value_indexes=gm["cfg_packed_key_value_indexes"], enable_taylorseer=args.taylorseer,
+            dedup_identical_branches=args.dedup_identical_branches, **gi)
 
     # FLUX VAE decoder (random-init at the true FLUX dims); images are decoded by the rank that owns them
     from bagel_amd.config import VAEDims
@@ -246,7 +250,7 @@ def main():
                                    f"num_timesteps={args.num_timesteps}, cfg_text 4.0 + cfg_img 1.5, "
                                    f"cfg_interval (0.4,1.0), global renorm, random-init weights, 34-token context; "
                                    f"one step = one generate_image call for the batch + VAE decode to uint8 of every image",
-                       "ranks": ranks_info, "taylorseer": bool(args.taylorseer), "global_batch": B, "units_per_rank_per_cfg_step": 3, "parallelism": f"cfg-branch x batch over {world} GPU"},
+                       "ranks": ranks_info, "taylorseer": bool(args.taylorseer), "dedup_identical_branches": bool(args.dedup_identical_branches), "global_batch": B, "units_per_rank_per_cfg_step": 3, "parallelism": f"cfg-branch x batch over {world} GPU"},
         }
         if events:
             # the dominant launch shape: all CFG branches packed (M = 3 x 4096 rows); the cond-only steps' smaller

@@ -61,6 +61,17 @@ int bagel_skinny_gemm_residual_rmsnorm_bf16(const void* X, long ldx, const void*
                                             void* Xn, long ldn, float eps, void* workspace, long workspace_bytes,
                                             void* stream);
 
+/* C = epilogue(RMSNorm(X; norm_weight, eps) . W^T): Qwen2RMSNorm (modeling_qwen2.py:54-59) followed by nn.Linear, for
+ * the one-token-per-sample decode loop (input_layernorm + q/k/v_proj, post_attention_layernorm + gate/up_proj, final
+ * norm + lm_head: qwen2_navit.py:798-801, 826-832, 1098-1105, 1204).  With at most 4 rows (2 for SwiGLU and for
+ * N > 16384) and K % 512 == 0 the rows are normalised inside the weight-streaming kernel and nothing else is
+ * launched; otherwise RMSNorm runs into the caller's Xn rows ([M][ldn], may be NULL when the fused form applies:
+ * bagel_skinny_gemv_eligible) and the split-K form follows.  epilogue: BAGEL_SK_BIAS, BAGEL_SK_SWIGLU, BAGEL_SK_BIAS_SILU. */
+int bagel_skinny_gemv_eligible(int M, int N, int K, int epilogue);
+int bagel_skinny_gemm_rmsnorm_in_bf16(const void* X, long ldx, const void* norm_weight, float eps, const void* W, long ldw,
+                                      void* C, long ldc, int M, int N, int K, const void* bias, int epilogue, void* Xn,
+                                      long ldn, void* workspace, long workspace_bytes, void* stream);
+
 /* out[r] = w * bf16(x[r] * rsqrt(mean(x[r]^2) + eps)); rows < split_row use w_first, the rest w_second.
  * Replaces Qwen2RMSNorm (modeling_qwen2.py:54-59) as used per modality at qwen2_navit.py:798-800,
  * 826-829 and 1102-1104. */
@@ -151,6 +162,8 @@ typedef struct bagel_mot_rows {        /* one packed forward: activations, table
 
 #define BAGEL_LAYER_KV_ONLY 1  /* stop once the layer's keys/values are in K_ws / Vt_ws (last layer of a prefill) */
 #define BAGEL_LAYER_XN_READY 2 /* Xn already holds input_layernorm(X): the previous layer's call produced it */
+#define BAGEL_LAYER_NORM_IN_GEMM 4 /* rows_gen == 0, a few rows: both RMSNorms run inside the projections that consume
+                                      them (bagel_skinny_gemm_rmsnorm_in_bf16); Xn is written only for next_norm_und */
 
 /* One layer, in place on r->X.  K_ws [Hkv][S][D] and Vt_ws [Hkv][D][S] are THIS layer's workspace slices.
  * next_norm_gen / next_norm_und (optional): weights of the RMSNorm that follows the layer (the next layer's

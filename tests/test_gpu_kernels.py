@@ -115,6 +115,55 @@ def test_skinny_swiglu():
     _close(C, ref, ulps=3.0, what="skinny swiglu")
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 6])
+@pytest.mark.parametrize("N,K", [(512, 512), (4608, 3584), (3584, 18944), (1008, 1024)])
+def test_skinny_gemv_shapes(M, N, K):
+    """Shapes with K a multiple of 512: at one to four rows these take the one-launch form (a wave owns whole weight
+    rows), above that the split-K form; both must agree with the same fp32 statement."""
+    k = _K()
+    X, W, b = _rand((M, K), 1.0, 40), _rand((N, K), 0.03, 41), _rand((N,), 0.5, 42)
+    ws = torch.empty(k.skinny_workspace_bytes(M, N), dtype=torch.uint8, device=DEV)
+    C = torch.full((M, N), float("nan"), dtype=BF16, device=DEV)
+    k.skinny_gemm(X.to(DEV), W.to(DEV), C, ws, bias=b.to(DEV))
+    _close(C, (X.float() @ W.float().t() + b.float()).to(BF16), what="gemv bias")
+    R = _rand((M, N), 1.0, 43)
+    Xr = R.to(DEV).clone()
+    k.skinny_gemm(X.to(DEV), W.to(DEV), Xr, ws, residual=Xr, epilogue=k.SK_RESIDUAL)
+    _close(Xr, ((X.float() @ W.float().t()).to(BF16).float() + R.float()).to(BF16), what="gemv residual")
+
+
+@pytest.mark.parametrize("M", [1, 2, 4, 6])
+@pytest.mark.parametrize("epi", ["bias", "swiglu", "bias_silu"])
+def test_skinny_gemm_rmsnorm_in(M, epi):
+    """RMSNorm applied inside the weight-streaming kernel against the two-launch statement of the same thing
+    (bagel_rmsnorm_bf16, then bagel_skinny_gemm_bf16): the normalised rows round to bf16 at the same two points,
+    so only the fp32 summation order differs."""
+    k = _K()
+    from bagel_amd.engine import _interleave_gate_up
+    Kd, N = 3584, 4608
+    X = _rand((M, Kd), 3.0, 50).to(DEV)
+    nw = (_rand((Kd,), 0.1, 51) + 1).to(BF16).to(DEV)
+    if epi == "swiglu":
+        W = _interleave_gate_up(_rand((N // 2, Kd), 0.03, 52), _rand((N // 2, Kd), 0.03, 53)).to(DEV)
+        code, b, ncol = k.SK_SWIGLU, None, N // 2
+    else:
+        W, b, ncol = _rand((N, Kd), 0.03, 52).to(DEV), _rand((N,), 0.5, 54).to(DEV), N
+        code = k.SK_BIAS if epi == "bias" else k.SK_BIAS_SILU
+    ws = torch.empty(k.skinny_workspace_bytes(M, N), dtype=torch.uint8, device=DEV)
+    Xn = torch.empty((M, Kd), dtype=BF16, device=DEV)
+    ref = torch.empty((M, ncol), dtype=BF16, device=DEV)
+    k.rmsnorm(X, Xn, nw, nw, M, 1e-6)
+    k.skinny_gemm(Xn, W, ref, ws, bias=b, epilogue=code)
+    got = torch.full((M, ncol), float("nan"), dtype=BF16, device=DEV)
+    scratch = torch.empty((M, Kd), dtype=BF16, device=DEV)
+    k.skinny_gemm_rmsnorm_in(X, nw, 1e-6, W, got, ws, Xn=scratch, bias=b, epilogue=code)
+    _close(got, ref, ulps=3.0 if epi != "bias" else 2.0, what=f"rmsnorm-in {epi} M={M}")
+    # and against the checker's own RMSNorm + fp32 matmul
+    xn = O.rms_norm(X.cpu(), nw.cpu(), 1e-6).float()
+    if epi == "bias":
+        _close(got, (xn @ W.cpu().float().t() + b.cpu().float()).to(BF16), what="rmsnorm-in vs checker")
+
+
 @pytest.mark.parametrize("rows,H,split", [(5, 256, 3), (4098, 3584, 4096), (130, 896, 0)])
 def test_rmsnorm(rows, H, split):
     k = _K()

@@ -232,3 +232,50 @@ def test_taylorseer_skipped_steps_ignore_x_t():
     run_scenario_on_gpu(sc, run, trace=b, teacher_x=xs2)
     for i in range(n):
         assert torch.equal(a[i]["v_cond"], b[i]["v_cond"]), i
+
+
+def test_dedup_identical_branches_changes_nothing():
+    """Text-to-image gives the image-free CFG branch the conditional branch's context: with
+    dedup_identical_branches that branch is not run.  Same latents bit for bit, with and without; a branch with a
+    different context is never aliased."""
+    import dataclasses
+    from tests.gpu_common import gpu_model, to_gpu_cache
+    sc = SCENARIOS["tiny_batch2"]             # batch of two images; the conditional cache also serves as the image-free one
+    run = OracleRun(sc)
+    model = gpu_model(sc, run.sd)
+    L = sc.dims.num_layers
+    cond = to_gpu_cache(run.ctx["cond"][0], L)
+    text = to_gpu_cache(run.ctx["text"][0], L)
+    gi, gt, gm = run.gi, run.gt, run.gm
+
+    def go(img_cache, dedup, trace):
+        return model.generate_image(
+            past_key_values=cond, num_timesteps=sc.num_timesteps, timestep_shift=sc.timestep_shift,
+            cfg_renorm_min=sc.cfg_renorm_min, cfg_renorm_type=sc.cfg_renorm_type, cfg_interval=list(sc.cfg_interval),
+            cfg_text_scale=sc.cfg_text_scale, cfg_text_past_key_values=text,
+            cfg_text_packed_position_ids=gt["cfg_packed_position_ids"],
+            cfg_text_packed_query_indexes=gt["cfg_packed_query_indexes"], cfg_text_key_values_lens=gt["cfg_key_values_lens"],
+            cfg_text_packed_key_value_indexes=gt["cfg_packed_key_value_indexes"], cfg_img_scale=sc.cfg_img_scale,
+            cfg_img_past_key_values=img_cache, cfg_img_packed_position_ids=gm["cfg_packed_position_ids"],
+            cfg_img_packed_query_indexes=gm["cfg_packed_query_indexes"], cfg_img_key_values_lens=gm["cfg_key_values_lens"],
+            cfg_img_packed_key_value_indexes=gm["cfg_packed_key_value_indexes"], trace=trace,
+            dedup_identical_branches=dedup, **gi)
+
+    ta, tb, tc = [], [], []
+    a = go(cond, False, ta)
+    b = go(cond, True, tb)                       # the same cache object: aliased
+    assert len(ta) == len(tb) and model.engine.kws is not None
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    for ra, rb in zip(ta, tb):
+        assert set(ra) == set(rb)
+        for k in ra:
+            assert torch.equal(ra[k], rb[k]), k
+    # an equal-valued but separately stored context is not aliased (nothing is compared by value): still the same result
+    from bagel_amd.modeling import NaiveCache
+    other = NaiveCache(L)
+    for l in range(L):
+        other.key_cache[l], other.value_cache[l] = cond.key_cache[l].clone(), cond.value_cache[l].clone()
+    c = go(other, True, tc)
+    for x, y in zip(a, c):
+        assert torch.equal(x, y)

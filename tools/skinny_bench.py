@@ -13,37 +13,40 @@ SHAPES = [("qkv", 4608, 3584, K.SK_BIAS), ("o_proj", 3584, 3584, K.SK_RESIDUAL),
 
 def main():
     dev = "cuda:0"
-    for M in [int(v) for v in sys.argv[1:]] or [6, 1]:
-        total_t = total_b = 0.0
-        for name, N, Kd, epi in SHAPES:
-            X = torch.randn((M, Kd), device=dev, dtype=torch.bfloat16)
-            # several copies of the weight so that successive launches do not hit the 256 MB Infinity Cache
-            copies = max(2, int(600e6 // (N * Kd * 2)) + 1)
-            Ws = [torch.randn((N, Kd), device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(copies)]
-            ncol = N // 2 if epi == K.SK_SWIGLU else N
-            C = torch.empty((M, ncol), device=dev, dtype=torch.bfloat16)
-            R = torch.randn((M, ncol), device=dev, dtype=torch.bfloat16) if epi == K.SK_RESIDUAL else None
-            b = torch.randn((N,), device=dev, dtype=torch.bfloat16) if epi == K.SK_BIAS else None
-            ws = torch.empty((16 * M * N,), device=dev, dtype=torch.float32)
-            for W in Ws:
-                K.skinny_gemm(X, W, C, ws, bias=b, residual=R, epilogue=epi)
-            times = []
-            for it in range(12):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                K.skinny_gemm(X, Ws[it % copies], C, ws, bias=b, residual=R, epilogue=epi)
-                e1.record()
-                torch.cuda.synchronize()
-                times.append(e0.elapsed_time(e1))
-            times.sort()
-            med = times[len(times) // 2]
-            nbytes = N * Kd * 2
-            if name != "lm_head":
-                total_t += med
-                total_b += nbytes
-            print(f"M={M:2d} {name:8s} N={N:6d} K={Kd:5d}: median {med * 1e3:7.1f} us  {nbytes / med / 1e6:6.0f} GB/s", flush=True)
-            del Ws
-        print(f"M={M:2d} one layer (4 projections): {total_t * 1e3:.1f} us  {total_b / total_t / 1e6:.0f} GB/s", flush=True)
+    for gemv in (0, 1):                     # 0: split-K MFMA form + reduce launch, 1: one-launch form (a wave owns whole rows)
+      K.lib().bagel_set_skinny_gemv(gemv)
+      print(f"--- form {gemv}")
+      for M in [int(v) for v in sys.argv[1:]] or [6, 1]:
+          total_t = total_b = 0.0
+          for name, N, Kd, epi in SHAPES:
+              X = torch.randn((M, Kd), device=dev, dtype=torch.bfloat16)
+              # several copies of the weight so that successive launches do not hit the 256 MB Infinity Cache
+              copies = max(2, int(600e6 // (N * Kd * 2)) + 1)
+              Ws = [torch.randn((N, Kd), device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(copies)]
+              ncol = N // 2 if epi == K.SK_SWIGLU else N
+              C = torch.empty((M, ncol), device=dev, dtype=torch.bfloat16)
+              R = torch.randn((M, ncol), device=dev, dtype=torch.bfloat16) if epi == K.SK_RESIDUAL else None
+              b = torch.randn((N,), device=dev, dtype=torch.bfloat16) if epi == K.SK_BIAS else None
+              ws = torch.empty((16 * M * N,), device=dev, dtype=torch.float32)
+              for W in Ws:
+                  K.skinny_gemm(X, W, C, ws, bias=b, residual=R, epilogue=epi)
+              times = []
+              for it in range(12):
+                  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                  e0.record()
+                  K.skinny_gemm(X, Ws[it % copies], C, ws, bias=b, residual=R, epilogue=epi)
+                  e1.record()
+                  torch.cuda.synchronize()
+                  times.append(e0.elapsed_time(e1))
+              times.sort()
+              med = times[len(times) // 2]
+              nbytes = N * Kd * 2
+              if name != "lm_head":
+                  total_t += med
+                  total_b += nbytes
+              print(f"M={M:2d} {name:8s} N={N:6d} K={Kd:5d}: median {med * 1e3:7.1f} us  {nbytes / med / 1e6:6.0f} GB/s", flush=True)
+              del Ws
+          print(f"M={M:2d} one layer (4 projections): {total_t * 1e3:.1f} us  {total_b / total_t / 1e6:.0f} GB/s", flush=True)
 
 
 if __name__ == "__main__":
