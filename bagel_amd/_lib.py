@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libbagel_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "bagel_hip.h")
-SOURCES = ["capi.hip", "gemm.hip", "skinny.hip", "attention.hip", "elementwise.hip", "vae.hip", "layer.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "skinny.hip", "attention.hip", "elementwise.hip", "vae.hip", "layer.hip", "decode_attention.hip"]
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -87,9 +87,12 @@ def lib() -> ctypes.CDLL:
         if stamp != source_digest() and os.environ.get("BAGEL_ALLOW_STALE_LIB") != "1":
             raise RuntimeError(f"{LIB_PATH} was not built from the sources in {CSRC} (digest mismatch): run "
                                "`python -c 'import __graft_entry__ as g; g.build()'`")
-        _lib = ctypes.CDLL(LIB_PATH)
+        # development: an A/B build of the same sources with other flags (tools/build_variant.py)
+        variant = os.environ.get("BAGEL_LIB_VARIANT")
+        _lib = ctypes.CDLL(variant if variant else LIB_PATH)
         _lib.bagel_last_error.restype = ctypes.c_char_p
-        for name in ("bagel_skinny_gemm_workspace_bytes", "bagel_cfg_workspace_bytes", "bagel_groupnorm_workspace_bytes"):
+        for name in ("bagel_skinny_gemm_workspace_bytes", "bagel_cfg_workspace_bytes", "bagel_groupnorm_workspace_bytes",
+                     "bagel_decode_attention_workspace_bytes"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = ctypes.c_long
     return _lib
@@ -160,15 +163,16 @@ def skinny_workspace_bytes(M, N):
     return lib().bagel_skinny_gemm_workspace_bytes(I(M), I(N))
 
 
-def skinny_gemm(X, W, C, workspace, bias=None, residual=None, epilogue=SK_BIAS):
+def skinny_gemm(X, W, C, workspace, bias=None, residual=None, epilogue=SK_BIAS, gemv=False):
+    """gemv=True: the decode loop's one-launch form where the shape allows it (bagel_skinny_gemv_bf16)."""
     M, K = X.shape
     N = W.shape[0]
     assert X.dtype == W.dtype == C.dtype == torch.bfloat16 and W.shape[1] == K
-    _check(lib().bagel_skinny_gemm_bf16(_p(X), L(X.stride(0)), _p(W), L(W.stride(0)), _p(C), L(C.stride(0)), I(M), I(N),
-                                        I(K), _p(bias), _p(residual),
-                                        L(residual.stride(0) if residual is not None else 0), I(epilogue),
-                                        _p(workspace), L(workspace.numel() * workspace.element_size()), _stream()),
-           "bagel_skinny_gemm_bf16")
+    fn, name = (lib().bagel_skinny_gemv_bf16, "bagel_skinny_gemv_bf16") if gemv else \
+               (lib().bagel_skinny_gemm_bf16, "bagel_skinny_gemm_bf16")
+    _check(fn(_p(X), L(X.stride(0)), _p(W), L(W.stride(0)), _p(C), L(C.stride(0)), I(M), I(N), I(K), _p(bias), _p(residual),
+              L(residual.stride(0) if residual is not None else 0), I(epilogue), _p(workspace),
+              L(workspace.numel() * workspace.element_size()), _stream()), name)
     return C
 
 
@@ -292,7 +296,8 @@ class MotLayer(ctypes.Structure):
 class MotRows(ctypes.Structure):
     _fields_ = [("rows_gen", I), ("rows_und", I), ("X", VP), ("Xn", VP), ("QKV", VP), ("Q", VP), ("O", VP), ("Hm", VP),
                 ("cos_table", VP), ("sin_table", VP), ("row_cs", VP), ("row_slot", VP), ("tiles", VP), ("n_tiles", I),
-                ("S", L), ("skinny_ws", VP), ("skinny_ws_bytes", L), ("und_rounding", I)]
+                ("S", L), ("skinny_ws", VP), ("skinny_ws_bytes", L), ("und_rounding", I),
+                ("decode_ws", VP), ("decode_ws_bytes", L)]
 
 
 def _addr(t):
@@ -300,11 +305,31 @@ def _addr(t):
 
 
 def mot_rows(rows_gen, rows_und, X, Xn, QKV, Q, O, Hm, cos_t, sin_t, row_cs, row_slot, tiles, n_tiles, S, skinny_ws,
-             und_rounding=False) -> MotRows:
-    """The per-forward argument block of mot_forward; the tensors must outlive the call."""
+             und_rounding=False, decode_ws=None) -> MotRows:
+    """The per-forward argument block of mot_forward; the tensors must outlive the call.  decode_ws (zeroed once by the
+    caller, decode_attention_workspace_bytes) lets a decode step run its attention in one launch."""
     return MotRows(rows_gen, rows_und, _addr(X), _addr(Xn), _addr(QKV), _addr(Q), _addr(O), _addr(Hm), _addr(cos_t),
                    _addr(sin_t), _addr(row_cs), _addr(row_slot), _addr(tiles), n_tiles, S, _addr(skinny_ws),
-                   skinny_ws.numel() * skinny_ws.element_size(), 1 if und_rounding else 0)
+                   skinny_ws.numel() * skinny_ws.element_size(), 1 if und_rounding else 0, _addr(decode_ws),
+                   0 if decode_ws is None else decode_ws.numel() * decode_ws.element_size())
+
+
+def decode_attention_supported(rows, Hq, Hkv, D) -> bool:
+    return bool(lib().bagel_decode_attention_supported(I(rows), I(Hq), I(Hkv), I(D)))
+
+
+def decode_attention_workspace_bytes(rows, Hq, Hkv, D) -> int:
+    return int(lib().bagel_decode_attention_workspace_bytes(I(rows), I(Hq), I(Hkv), I(D)))
+
+
+def decode_attention(qkv, Hq, Hkv, D, q_norm, k_norm, cos_t, sin_t, row_cs, row_slot, tiles, K_ws, Vt_ws, S, O, eps,
+                     und_rounding, workspace):
+    """One new token per row: q/k norm + RoPE, KV write and attention in one launch (bagel_decode_attention_bf16)."""
+    _check(lib().bagel_decode_attention_bf16(_p(qkv), L(qkv.stride(0)), I(qkv.shape[0]), I(Hq), I(Hkv), I(D), _p(q_norm),
+                                             _p(k_norm), _p(cos_t), _p(sin_t), _p(row_cs), _p(row_slot), _p(tiles), _p(K_ws),
+                                             _p(Vt_ws), L(S), _p(O), F(eps), I(1 if und_rounding else 0), _p(workspace),
+                                             L(workspace.numel() * workspace.element_size()), _stream()),
+           "bagel_decode_attention_bf16")
 
 
 def mot_forward(dims: MotDims, layers, n_layers, rows: MotRows, K_ws, Vt_ws, kv_only_last=False, final_norm_gen=None,

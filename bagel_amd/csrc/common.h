@@ -27,10 +27,42 @@ __device__ __forceinline__ float gelu_tanh_f32(float x) {
 // SwiGLU epilogue runs this on every gate value of a 256 x 256 tile while the matrix pipe waits.
 __device__ __forceinline__ float silu_f32(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// ---- cross-lane reductions without LDS round trips.  A butterfly over lanes i ^ 1, i ^ 2, ... only needs, at each
+// step, SOME lane of the partner group (all lanes of a group already agree), so the steps are DPP row operations
+// (quad permutes, half-row and row mirrors) and, across the 16-lane rows, the gfx950 lane swaps.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+
+template <typename OP>
+__device__ __forceinline__ float row_reduce(float v, OP op) {   // over the 16 lanes of a DPP row
+  v = op(v, dpp_f32<DPP_XOR1>(v));
+  v = op(v, dpp_f32<DPP_XOR2>(v));
+  v = op(v, dpp_f32<DPP_HALF_MIRROR>(v));
+  return op(v, dpp_f32<DPP_ROW_MIRROR>(v));
+}
+template <typename OP>
+__device__ __forceinline__ float wave_reduce(float v, OP op) {
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_;
+  v = row_reduce(v, op);
+  const u32x2_ a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = op(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const u32x2_ b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return op(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  return wave_reduce(v, [](float a, float b) { return a + b; });
+}
+__device__ __forceinline__ float wave_max(float v) {
+  return wave_reduce(v, [](float a, float b) { return fmaxf(a, b); });
+}
+// sum over aligned groups of 8 lanes
+__device__ __forceinline__ float group8_sum(float v) {
+  v += dpp_f32<DPP_XOR1>(v);
+  v += dpp_f32<DPP_XOR2>(v);
+  return v + dpp_f32<DPP_HALF_MIRROR>(v);
 }
 
 // Host-side error reporting shared by every entry point (see capi.hip).

@@ -3,6 +3,7 @@
 // Euler update.  All loads/stores of bf16 rows are 16 bytes per lane.  Rounding points follow the
 // reference's bf16 graph; each kernel names the lines it restates.
 #include "common.h"
+#include "qk_rope.h"
 
 // ---------------------------------------------------------------------------------------------
 // RMSNorm over rows of [rows, H]; rows < split use w_first, the others w_second.
@@ -119,39 +120,9 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16* __restric
   const bool is_q = head < Hq;
   const bf16* src = qkv + (long)row * ld + (long)head * D + 8 * j;  // q heads then k heads are contiguous
   const bf16x8 v = *(const bf16x8*)src;
-  float x[8];
-  float ss = 0.f;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    x[e] = (float)v[e];
-    ss += x[e] * x[e];
-  }
-#pragma unroll
-  for (int o = LPH / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, LPH);
-  const float rs = rsqrtf(ss / (float)D + eps);
   const bf16* w = is_q ? (row < split ? qw_first : qw_second) : (row < split ? kw_first : kw_second);
-  const bf16x8 wv = *(const bf16x8*)(w + 8 * j);
-  const long cs = (long)row_cs[row] * D + 8 * j;
-  const bf16x8 cv = *(const bf16x8*)(cos_t + cs);
-  const bf16x8 sv = *(const bf16x8*)(sin_t + cs);
-  float y[8], yr[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float n = x[e] * rs;
-    y[e] = und_rounding ? round_bf16((float)wv[e] * round_bf16(n)) : (float)wv[e] * n;
-  }
-  const float sign = j < LPH / 2 ? -1.f : 1.f;  // rotate_half: first half gets -x2, second half +x1
-#pragma unroll
-  for (int e = 0; e < 8; ++e) yr[e] = sign * __shfl_xor(y[e], LPH / 2, LPH);
-  bf16x8 o;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float c = (float)cv[e], s = (float)sv[e];
-    if (und_rounding)
-      o[e] = (bf16)(round_bf16(y[e] * c) + round_bf16(yr[e] * s));
-    else
-      o[e] = (bf16)(__fmul_rn(y[e], c) + __fmul_rn(yr[e], s));
-  }
+  const long cs = (long)row_cs[row] * D;
+  const bf16x8 o = qk_norm_rope_lane<D>(v, j, w, cos_t + cs, sin_t + cs, eps, und_rounding);
   if (is_q)
     *(bf16x8*)(Q + ((long)row * Hq + head) * D + 8 * j) = o;
   else
@@ -572,8 +543,8 @@ extern "C" int bagel_cfg_euler_update_static(const void* v_cond, const void* v_t
 // Greedy token choice: out[r] = index of the first maximum of logits[r] (torch.argmax, bagel.py:1580).
 // One block per row; ties resolve to the lowest index, NaNs are never selected over numbers.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void argmax_rows_kernel(const bf16* __restrict__ logits, long ld, int n,
-                                                          int* __restrict__ out) {
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const bf16* __restrict__ logits, long ld, int n,
+                                                           int* __restrict__ out) {
   const bf16* row = logits + (long)blockIdx.x * ld;
   float best = -INFINITY;
   int bi = 0x7fffffff;
@@ -583,37 +554,46 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const bf16* __restrict
       bi = i;
     }
   };
-  // 16-byte loads where the row allows it (a vocabulary row is ~300 KB), scalar loads for the ragged rest
+  // 16-byte loads where the row allows it (a vocabulary row is ~300 KB), four of them in flight per thread; scalar
+  // loads for the ragged rest
   const bool vec = (ld % 8 == 0) && ((uintptr_t)logits % 16 == 0);
   const int nvec = vec ? n / 8 : 0;
-  for (int c = threadIdx.x; c < nvec; c += 256) {
-    const bf16x8 v = *(const bf16x8*)(row + 8 * c);
+  for (int c0 = threadIdx.x; c0 < nvec; c0 += 4096) {
+    bf16x8 v[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) take((float)v[e], 8 * c + e);
-  }
-  for (int i = nvec * 8 + threadIdx.x; i < n; i += 256) take((float)row[i], i);
-  __shared__ float sv[256];
-  __shared__ int si[256];
-  sv[threadIdx.x] = best;
-  si[threadIdx.x] = bi;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) {
-      const float v = sv[threadIdx.x + o];
-      const int i = si[threadIdx.x + o];
-      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) {
-        sv[threadIdx.x] = v;
-        si[threadIdx.x] = i;
+    for (int u = 0; u < 4; ++u)
+      if (c0 + 1024 * u < nvec) v[u] = *(const bf16x8*)(row + 8 * (c0 + 1024 * u));
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (c0 + 1024 * u < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) take((float)v[u][e], 8 * (c0 + 1024 * u) + e);
       }
-    }
-    __syncthreads();
   }
-  if (threadIdx.x == 0) out[blockIdx.x] = si[0] == 0x7fffffff ? 0 : si[0];
+  for (int i = nvec * 8 + threadIdx.x; i < n; i += 1024) take((float)row[i], i);
+  // wave reduce, then the 16 wave winners through LDS
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float v = __shfl_xor(best, o, 64);
+    const int i = __shfl_xor(bi, o, 64);
+    take(v, i);
+  }
+  __shared__ float sv[16];
+  __shared__ int si[16];
+  if ((threadIdx.x & 63) == 0) {
+    sv[threadIdx.x >> 6] = best;
+    si[threadIdx.x >> 6] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) take(sv[w], si[w]);
+    out[blockIdx.x] = bi == 0x7fffffff ? 0 : bi;
+  }
 }
 
 extern "C" int bagel_argmax_rows_bf16(const void* logits, long ld, int rows, int n, void* out_i32, void* stream) {
   BAGEL_CHECK(logits && out_i32 && rows > 0 && n > 0, "bagel_argmax_rows_bf16: bad arguments");
-  hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, ld, n,
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, (const bf16*)logits, ld, n,
                      (int*)out_i32);
   BAGEL_LAUNCH_CHECK();
   return 0;

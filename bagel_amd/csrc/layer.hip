@@ -93,20 +93,29 @@ extern "C" int bagel_mot_layer_forward(const bagel_mot_dims* d, const bagel_mot_
 
   if (flags & BAGEL_LAYER_NORM_IN_GEMM) {
     // understanding rows only, a handful of them (a decode step): both RMSNorms are applied inside the
-    // weight-streaming kernels that consume them, so the layer is seven launches and Xn is never written
+    // weight-streaming kernels that consume them, so the layer is seven launches (five with the one-launch decode attention) and Xn is never written
     BAGEL_CHECK(Mv == 0 && Mt <= 64, "bagel_mot_layer_forward: BAGEL_LAYER_NORM_IN_GEMM needs rows_gen == 0 and rows_und <= 64");
     TRY(bagel_skinny_gemm_rmsnorm_in_bf16(r->X, H, u.ln_in, eps, u.wqkv, H, r->QKV, qkv, Mt, qkv, H, u.bqkv, BAGEL_SK_BIAS, r->Xn,
                                           H, r->skinny_ws, r->skinny_ws_bytes, stream));
-    TRY(bagel_qk_norm_rope_kv_bf16(r->QKV, qkv, M, Hq, Hkv, D, u.q_norm, u.q_norm, u.k_norm, u.k_norm, M, r->cos_table,
-                                   r->sin_table, r->row_cs, r->row_slot, r->Q, K_ws, Vt_ws, r->S, eps, r->und_rounding, stream));
-    if (flags & BAGEL_LAYER_KV_ONLY) return 0;
-    BAGEL_CHECK(r->O && r->Hm && r->tiles && r->n_tiles > 0, "bagel_mot_layer_forward: null attention / MLP buffer");
-    TRY(bagel_varlen_attention_bf16(r->Q, K_ws, Vt_ws, r->O, r->tiles, r->n_tiles, Hq, Hkv, D, r->S, stream));
-    TRY(bagel_skinny_gemm_bf16(r->O, qd, u.wo, qd, r->X, H, Mt, H, qd, nullptr, r->X, H, BAGEL_SK_RESIDUAL, r->skinny_ws,
+    const bool one_launch = r->decode_ws && !(flags & BAGEL_LAYER_KV_ONLY) && r->n_tiles == M &&
+                            bagel_decode_attention_supported(M, Hq, Hkv, D);
+    if (one_launch) {
+      BAGEL_CHECK(r->O && r->Hm && r->tiles, "bagel_mot_layer_forward: null attention / MLP buffer");
+      TRY(bagel_decode_attention_bf16(r->QKV, qkv, M, Hq, Hkv, D, u.q_norm, u.k_norm, r->cos_table, r->sin_table, r->row_cs,
+                                      r->row_slot, r->tiles, K_ws, Vt_ws, r->S, r->O, eps, r->und_rounding, r->decode_ws,
+                                      r->decode_ws_bytes, stream));
+    } else {
+      TRY(bagel_qk_norm_rope_kv_bf16(r->QKV, qkv, M, Hq, Hkv, D, u.q_norm, u.q_norm, u.k_norm, u.k_norm, M, r->cos_table,
+                                     r->sin_table, r->row_cs, r->row_slot, r->Q, K_ws, Vt_ws, r->S, eps, r->und_rounding, stream));
+      if (flags & BAGEL_LAYER_KV_ONLY) return 0;
+      BAGEL_CHECK(r->O && r->Hm && r->tiles && r->n_tiles > 0, "bagel_mot_layer_forward: null attention / MLP buffer");
+      TRY(bagel_varlen_attention_bf16(r->Q, K_ws, Vt_ws, r->O, r->tiles, r->n_tiles, Hq, Hkv, D, r->S, stream));
+    }
+    TRY(bagel_skinny_gemv_bf16(r->O, qd, u.wo, qd, r->X, H, Mt, H, qd, nullptr, r->X, H, BAGEL_SK_RESIDUAL, r->skinny_ws,
                                r->skinny_ws_bytes, stream));
     TRY(bagel_skinny_gemm_rmsnorm_in_bf16(r->X, H, u.ln_post, eps, u.wgu, H, r->Hm, I, Mt, 2 * I, H, nullptr, BAGEL_SK_SWIGLU,
                                           r->Xn, H, r->skinny_ws, r->skinny_ws_bytes, stream));
-    TRY(bagel_skinny_gemm_bf16(r->Hm, I, u.wd, I, r->X, H, Mt, H, I, nullptr, r->X, H, BAGEL_SK_RESIDUAL, r->skinny_ws,
+    TRY(bagel_skinny_gemv_bf16(r->Hm, I, u.wd, I, r->X, H, Mt, H, I, nullptr, r->X, H, BAGEL_SK_RESIDUAL, r->skinny_ws,
                                r->skinny_ws_bytes, stream));
     if (next_norm_und) TRY(bagel_rmsnorm_bf16(r->X, H, r->Xn, H, M, H, next_norm_und, next_norm_und, M, eps, stream));
     return 0;

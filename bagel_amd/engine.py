@@ -606,14 +606,20 @@ class MoTEngine:
         steps_done = 0
         n_layers = len(w.layers)
         # one argument block for every step: only the three table pointers move (tables of all steps were built above)
-        rows = K.mot_rows(0, B, X, Xn, QKV, Q, O, Hm, cos, sin, row_cs[0], row_slot[0], tiles[0], B, S, skw, und_rounding=True)
+        # scratch of the one-launch decode attention (tickets + partial sums), zero when first allocated and left
+        # zero by every launch
+        dws = None
+        if K.decode_attention_supported(B, Hq, Hkv, D):
+            dws = self._get("attn_ws_dec", (K.decode_attention_workspace_bytes(B, Hq, Hkv, D),), dtype=torch.uint8, zero=True)
+        rows = K.mot_rows(0, B, X, Xn, QKV, Q, O, Hm, cos, sin, row_cs[0], row_slot[0], tiles[0], B, S, skw, und_rounding=True,
+                          decode_ws=dws)
         cs0, slot0, tile0 = row_cs.data_ptr(), row_slot.data_ptr(), tiles.data_ptr()
         table = w.layer_table()
         for t in range(max_length):
             K.gather_rows(w.embed_tokens, seq[t], X, B)
             rows.row_cs, rows.row_slot, rows.tiles = cs0 + 4 * B * t, slot0 + 4 * B * t, tile0 + 32 * B * t
-            # 28 layers in one C call.  Up to four samples: seven launches per layer, the RMSNorms run inside the
-            # weight-streaming kernels that consume them; more: o_proj / down_proj reduce their partial sums, add the
+            # 28 layers in one C call.  Up to four samples: five launches per layer (the RMSNorms run inside the
+            # weight-streaming kernels that consume them; q/k norm, RoPE, KV write and attention are one kernel); more: o_proj / down_proj reduce their partial sums, add the
             # residual and apply the RMSNorm that follows in one launch
             K.mot_forward(self._cdims, table, n_layers, rows, kws, vtws)
             # final norm + lm_head in one weight-streaming launch

@@ -68,6 +68,14 @@ int bagel_skinny_gemm_residual_rmsnorm_bf16(const void* X, long ldx, const void*
  * launched; otherwise RMSNorm runs into the caller's Xn rows ([M][ldn], may be NULL when the fused form applies:
  * bagel_skinny_gemv_eligible) and the split-K form follows.  epilogue: BAGEL_SK_BIAS, BAGEL_SK_SWIGLU, BAGEL_SK_BIAS_SILU. */
 int bagel_skinny_gemv_eligible(int M, int N, int K, int epilogue);
+
+/* bagel_skinny_gemm_bf16's contract in the one-launch form where bagel_skinny_gemv_eligible() accepts the shape (a wave
+ * owns whole weight rows: no partial sums, other fp32 summation order), the split-K form otherwise.  For the decode
+ * loop; bagel_skinny_gemm_bf16 itself always takes the split-K form, so that a row's result never depends on how many
+ * rows share the launch. */
+int bagel_skinny_gemv_bf16(const void* X, long ldx, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
+                           const void* bias, const void* residual, long ldr, int epilogue, void* workspace,
+                           long workspace_bytes, void* stream);
 int bagel_skinny_gemm_rmsnorm_in_bf16(const void* X, long ldx, const void* norm_weight, float eps, const void* W, long ldw,
                                       void* C, long ldc, int M, int N, int K, const void* bias, int epilogue, void* Xn,
                                       long ldn, void* workspace, long workspace_bytes, void* stream);
@@ -158,12 +166,32 @@ typedef struct bagel_mot_rows {        /* one packed forward: activations, table
   void* skinny_ws;                     /* fp32 split-K partials: bagel_skinny_gemm_workspace_bytes(min(rows_und, 64), 2I) */
   long skinny_ws_bytes;
   int und_rounding;                    /* mode="und" rounding of the q/k norm and RoPE (qwen2_navit.py:526-530) */
+  void* decode_ws;                     /* optional, for BAGEL_LAYER_NORM_IN_GEMM: bagel_decode_attention_workspace_bytes(),
+                                          zeroed once by the caller; every row is then one sample's single new token
+                                          and tiles[i] describes row i */
+  long decode_ws_bytes;
 } bagel_mot_rows;
 
 #define BAGEL_LAYER_KV_ONLY 1  /* stop once the layer's keys/values are in K_ws / Vt_ws (last layer of a prefill) */
 #define BAGEL_LAYER_XN_READY 2 /* Xn already holds input_layernorm(X): the previous layer's call produced it */
 #define BAGEL_LAYER_NORM_IN_GEMM 4 /* rows_gen == 0, a few rows: both RMSNorms run inside the projections that consume
                                       them (bagel_skinny_gemm_rmsnorm_in_bf16); Xn is written only for next_norm_und */
+
+/* A decode step's attention in one launch: q/k RMSNorm + RoPE of row i, its new key / value written to slot
+ * row_slot[i] of K_ws / Vt_ws, attention of the row over keys [kv_start, kv_start + kv_len) of tiles[i] (the new
+ * slot included), O[i] = result.  Equivalent to bagel_qk_norm_rope_kv_bf16 + bagel_varlen_attention_bf16 on rows that
+ * are each one sample's single new token (Bagel.generate_text, bagel.py:1551-1587; qwen2_navit.py:549-599), with the
+ * keys of a sample split over workgroups and merged by the last one to finish.
+ * workspace: bagel_decode_attention_workspace_bytes(), its first 256 bytes zero before the first call (the kernel
+ * leaves them zero); calls sharing a workspace must not overlap.  Same finite-padding precondition on Vt_ws as
+ * bagel_varlen_attention_bf16.  bagel_decode_attention_supported() != 0: rows * Hkv <= 64, Hq / Hkv 7 or 2,
+ * head_dim 128 or 64. */
+int bagel_decode_attention_supported(int rows, int Hq, int Hkv, int head_dim);
+long bagel_decode_attention_workspace_bytes(int rows, int Hq, int Hkv, int head_dim);
+int bagel_decode_attention_bf16(const void* qkv, long ld, int rows, int Hq, int Hkv, int head_dim, const void* q_norm,
+                                const void* k_norm, const void* cos_table, const void* sin_table, const void* row_cs,
+                                const void* row_slot, const void* tiles, void* K_ws, void* Vt_ws, long S, void* O,
+                                float eps, int und_rounding, void* workspace, long workspace_bytes, void* stream);
 
 /* One layer, in place on r->X.  K_ws [Hkv][S][D] and Vt_ws [Hkv][D][S] are THIS layer's workspace slices.
  * next_norm_gen / next_norm_und (optional): weights of the RMSNorm that follows the layer (the next layer's

@@ -103,6 +103,21 @@ def test_skinny_gemm(M, N, K):
     _close(C3, torch.nn.functional.silu((X.float() @ W.float().t() + b.float()).to(BF16)), ulps=3.0, what="skinny silu")
 
 
+def test_skinny_gemm_row_count_invariance():
+    """bagel_skinny_gemm_bf16: a row's result does not depend on how many rows share the launch (the packed CFG branches
+    rely on it)."""
+    k = _K()
+    N, Kd = 3584, 3584
+    X, W, b = _rand((6, Kd), 1.0, 17).to(DEV), _rand((N, Kd), 0.03, 18).to(DEV), _rand((N,), 0.5, 19).to(DEV)
+    ws = torch.empty(k.skinny_workspace_bytes(6, N), dtype=torch.uint8, device=DEV)
+    C6 = torch.empty((6, N), dtype=BF16, device=DEV)
+    k.skinny_gemm(X, W, C6, ws, bias=b)
+    for rows in (1, 2, 4):
+        C = torch.empty((rows, N), dtype=BF16, device=DEV)
+        k.skinny_gemm(X[:rows], W, C, ws, bias=b)
+        assert torch.equal(C, C6[:rows])
+
+
 def test_skinny_swiglu():
     k = _K()
     from bagel_amd.engine import _interleave_gate_up
@@ -124,11 +139,11 @@ def test_skinny_gemv_shapes(M, N, K):
     X, W, b = _rand((M, K), 1.0, 40), _rand((N, K), 0.03, 41), _rand((N,), 0.5, 42)
     ws = torch.empty(k.skinny_workspace_bytes(M, N), dtype=torch.uint8, device=DEV)
     C = torch.full((M, N), float("nan"), dtype=BF16, device=DEV)
-    k.skinny_gemm(X.to(DEV), W.to(DEV), C, ws, bias=b.to(DEV))
+    k.skinny_gemm(X.to(DEV), W.to(DEV), C, ws, bias=b.to(DEV), gemv=True)
     _close(C, (X.float() @ W.float().t() + b.float()).to(BF16), what="gemv bias")
     R = _rand((M, N), 1.0, 43)
     Xr = R.to(DEV).clone()
-    k.skinny_gemm(X.to(DEV), W.to(DEV), Xr, ws, residual=Xr, epilogue=k.SK_RESIDUAL)
+    k.skinny_gemm(X.to(DEV), W.to(DEV), Xr, ws, residual=Xr, epilogue=k.SK_RESIDUAL, gemv=True)
     _close(Xr, ((X.float() @ W.float().t()).to(BF16).float() + R.float()).to(BF16), what="gemv residual")
 
 
@@ -274,6 +289,72 @@ def test_varlen_attention_head_dim_64(q_lens, ctx_lens, Hq, Hkv, causal, form):
 def test_varlen_attention_running_max_jump(form):
     got, ref = _attention_case([130], [500], 2, 1, seed=41, spike=True, form=form)
     _close(got, ref, ulps=2.0, what="attention spike")
+
+
+@pytest.mark.parametrize("kv_lens,Hq,Hkv,D", [([10], 14, 2, 128), ([700], 28, 4, 128), ([65, 2500, 129], 14, 2, 128),
+                                               ([9035], 28, 4, 128), ([64, 321], 14, 2, 64), ([300, 1], 2, 1, 128)])
+@pytest.mark.parametrize("und_rounding", [True, False])
+def test_decode_attention_matches_three_launch_path(kv_lens, Hq, Hkv, D, und_rounding):
+    """One new token per sample: the one-launch kernel against bagel_qk_norm_rope_kv_bf16 + bagel_varlen_attention_bf16
+    on the same inputs.  The key / value caches must come out bit-identical (same arithmetic, same slots); the
+    outputs are held to the bar of the tiled kernel's own tests, against exact fp32 attention over those caches.
+    Two launches in a row on one workspace: the tickets must be back at zero after the first."""
+    k = _K()
+    B = len(kv_lens)
+    qkv_dim = (Hq + 2 * Hkv) * D
+    kv_start, s = [], 0
+    for n in kv_lens:
+        kv_start.append(s)
+        s += (n + 63) // 64 * 64
+    S = s
+    g = torch.Generator().manual_seed(61)
+    Kc = (torch.randn(Hkv, S, D, generator=g) * 1.0).to(BF16)
+    Vc = (torch.randn(Hkv, D, S, generator=g) * 1.0).to(BF16)
+    for b, n in enumerate(kv_lens):                 # padding and the new token's own slot: zero values, garbage keys
+        Vc[:, :, kv_start[b] + n - 1:kv_start[b] + (n + 63) // 64 * 64] = 0
+    qkv = _rand((B, qkv_dim), 1.5, 62).to(DEV)
+    qn, kn = (_rand((D,), 0.1, 63) + 1).to(BF16).to(DEV), (_rand((D,), 0.1, 64) + 1).to(BF16).to(DEV)
+    pos = torch.tensor([n + 5 for n in kv_lens])
+    cos, sin = O.rotary_cos_sin(pos, D, 1e6, BF16)
+    row_cs = torch.arange(B, dtype=torch.int32, device=DEV)
+    row_slot = torch.tensor([kv_start[b] + kv_lens[b] - 1 for b in range(B)], dtype=torch.int32, device=DEV)
+    tiles = torch.tensor([(b, 1, kv_start[b], kv_lens[b], -1, 0, 0, 0) for b in range(B)], dtype=torch.int32, device=DEV)
+    # three launches
+    K1, V1 = Kc.to(DEV).clone(), Vc.to(DEV).clone()
+    Q = torch.empty((B, Hq, D), dtype=BF16, device=DEV)
+    O1 = torch.empty((B, Hq * D), dtype=BF16, device=DEV)
+    k.qk_norm_rope_kv(qkv, B, Hq, Hkv, D, qn, qn, kn, kn, B, cos.to(DEV), sin.to(DEV), row_cs, row_slot, Q, K1, V1, S, 1e-6,
+                      und_rounding)
+    k.varlen_attention(Q, K1, V1, O1, tiles, B, Hq, Hkv, D, S)
+    rep = Hq // Hkv
+    exact = torch.empty((B, Hq, D))
+    for b, n in enumerate(kv_lens):
+        kk = K1[:, kv_start[b]:kv_start[b] + n].float().cpu().repeat_interleave(rep, dim=0)        # [Hq, n, D]
+        vv = V1[:, :, kv_start[b]:kv_start[b] + n].float().cpu().repeat_interleave(rep, dim=0)     # [Hq, D, n]
+        pr = torch.softmax(torch.einsum("hd,hnd->hn", Q[b].float().cpu(), kk) / math.sqrt(D), dim=-1)
+        exact[b] = torch.einsum("hn,hdn->hd", pr, vv)
+    exact = exact.reshape(B, Hq * D).to(BF16)
+
+    def near_exact(got, what):
+        # the bound of the tiled kernel's tests on the largest error; the share of elements within one ulp is taken
+        # at 0.99 because the smallest case has under two thousand outputs
+        err = (got.float().cpu() - exact.float()).abs()
+        top = float(exact.float().abs().max())
+        assert float(err.max()) <= 2.0 * 2.0 ** -8 * top + 1e-6, f"{what}: max-abs {float(err.max())}"
+        assert (err <= 2.0 ** -7 * exact.float().abs() + 1e-3 * top).float().mean() > 0.99, what
+
+    near_exact(O1, "tiled attention on one-row tiles")
+    # one launch, twice
+    assert k.decode_attention_supported(B, Hq, Hkv, D) == (Hq // Hkv in (2, 7))
+    ws = torch.zeros(k.decode_attention_workspace_bytes(B, Hq, Hkv, D), dtype=torch.uint8, device=DEV)
+    for _ in range(2):
+        K2, V2 = Kc.to(DEV).clone(), Vc.to(DEV).clone()
+        O2 = torch.full((B, Hq * D), float("nan"), dtype=BF16, device=DEV)
+        k.decode_attention(qkv, Hq, Hkv, D, qn, kn, cos.to(DEV), sin.to(DEV), row_cs, row_slot, tiles, K2, V2, S, O2, 1e-6,
+                           und_rounding, ws)
+        assert torch.equal(K2, K1) and torch.equal(V2, V1), "key / value caches differ"
+        assert int(ws[:256].view(torch.int32).abs().sum()) == 0, "tickets not returned to zero"
+        near_exact(O2, "decode attention")
 
 
 def test_varlen_attention_forms_agree():

@@ -14,7 +14,6 @@ SHAPES = [("qkv", 4608, 3584, K.SK_BIAS), ("o_proj", 3584, 3584, K.SK_RESIDUAL),
 def main():
     dev = "cuda:0"
     for gemv in (0, 1):                     # 0: split-K MFMA form + reduce launch, 1: one-launch form (a wave owns whole rows)
-      K.lib().bagel_set_skinny_gemv(gemv)
       print(f"--- form {gemv}")
       for M in [int(v) for v in sys.argv[1:]] or [6, 1]:
           total_t = total_b = 0.0
@@ -29,12 +28,12 @@ def main():
               b = torch.randn((N,), device=dev, dtype=torch.bfloat16) if epi == K.SK_BIAS else None
               ws = torch.empty((16 * M * N,), device=dev, dtype=torch.float32)
               for W in Ws:
-                  K.skinny_gemm(X, W, C, ws, bias=b, residual=R, epilogue=epi)
+                  K.skinny_gemm(X, W, C, ws, bias=b, residual=R, epilogue=epi, gemv=bool(gemv))
               times = []
               for it in range(12):
                   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                   e0.record()
-                  K.skinny_gemm(X, Ws[it % copies], C, ws, bias=b, residual=R, epilogue=epi)
+                  K.skinny_gemm(X, Ws[it % copies], C, ws, bias=b, residual=R, epilogue=epi, gemv=bool(gemv))
                   e1.record()
                   torch.cuda.synchronize()
                   times.append(e0.elapsed_time(e1))
