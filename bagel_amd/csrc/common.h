@@ -58,6 +58,17 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ float wave_max(float v) {
   return wave_reduce(v, [](float a, float b) { return fmaxf(a, b); });
 }
+// The value of lane ^ W (a true butterfly partner, whatever the lanes hold).
+template <int W>
+__device__ __forceinline__ float xor_lane(float v) {
+  static_assert(W == 1 || W == 2 || W == 4 || W == 8, "16 and 32 are the lane swaps");
+  if constexpr (W == 1) return dpp_f32<DPP_XOR1>(v);
+  if constexpr (W == 2) return dpp_f32<DPP_XOR2>(v);
+  if constexpr (W == 8) return dpp_f32<0x128>(v);   // row_ror:8
+  // no DPP control flips bit 2 alone: ds_swizzle in bit mode (and 0x1f, or 0, xor 4)
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x1F | (4 << 10)));
+}
+
 // sum over aligned groups of 8 lanes
 __device__ __forceinline__ float group8_sum(float v) {
   v += dpp_f32<DPP_XOR1>(v);

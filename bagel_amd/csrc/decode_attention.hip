@@ -7,15 +7,17 @@
 // attention kernel whose 128-row query tiles carry one live row); a decode step is latency, not throughput, so:
 //
 //   grid = (key chunks, kv heads, samples), 1024 threads.  A workgroup takes one sample, one kv head with the REP
-//   query heads that share it, and one chunk of that sample's keys (the whole sample up to 1024 keys).  Its four
-//   groups of four waves walk the chunk's 64-key tiles round-robin, each with its own online softmax, and are merged
-//   through LDS.  The first tile's keys and values are requested before anything else, so the norm + RoPE of the
+//   query heads that share it, and one chunk of that sample's keys (256 keys, more when the sample has over 8192).
+//   Its four groups of four waves take one 64-key tile each per round, each with its own online softmax, and are
+//   merged through LDS.  The first two rounds' keys and values are requested before anything else, so the norm + RoPE of the
 //   queries (a few hundred flops, recomputed by every workgroup) runs under that latency.  The workgroup whose
 //   chunk holds the new token's slot writes the new key / value to the workspace for later steps and patches them
 //   into its own registers from LDS, so nothing is read back from memory inside the launch.
-//   Longer contexts are split over workgroups, at least 1024 keys each: every workgroup leaves an unnormalised
-//   partial (max, sum, REP x D accumulators, fp32) and the last one of a (sample, kv head) to finish - found with
-//   one atomic ticket - merges them.  No workgroup ever waits for another.
+//   A sample of more than one chunk is split over workgroups: every workgroup leaves an unnormalised partial (max,
+//   sum, REP x D accumulators, fp32) and the last one of a (sample, kv head) to finish - found with one atomic
+//   ticket, released and acquired by one thread per workgroup - merges them.  No workgroup ever waits for another.
+//   (Measured inside the 7B decode step at 400-700 keys: 12.5 us against 22.9 us for the three launches; one
+//   workgroup per kv head walking all tiles took 15-21 us, a fence in every wave 27 us.)
 //
 // Products are plain VALU dot products (v_dot2_f32_bf16): one query row per head gives the matrix cores nothing to
 // do.  Arithmetic follows the tiled kernel: fp32 scores and statistics, P rounded to bf16 for P.V, fp32

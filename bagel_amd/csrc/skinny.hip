@@ -13,6 +13,7 @@
 // bias / SiLU / residual / SwiGLU, so results are bitwise reproducible.
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 
 enum { SK_BIAS = 0, SK_RESIDUAL = 1, SK_SWIGLU = 2, SK_BIAS_SILU = 3 };
 
@@ -155,32 +156,59 @@ __global__ __launch_bounds__(RN_THREADS) void skinny_reduce_rmsnorm_kernel(const
 }
 
 // ---------------------------------------------------------------------------------------------
-// At most 4 token rows (a decode step of up to four samples, the two text tokens of up to two units): a GEMV-shaped kernel with no
-// split-K and no partial sums.  A wave owns NF weight rows over the WHOLE reduction; its 64 lanes split K in
-// 16-byte pieces, so every load instruction reads 1 KiB that is contiguous in memory (the weight row itself),
-// up to three steps in flight behind the one being multiplied.  v_dot2c_f32_bf16 accumulates in fp32 per lane; the lanes'
-// sums are combined by a butterfly that halves the number of live values at every exchange, after which lane 4 v
-// holds output value v.  Bias / SiLU / residual / SwiGLU are applied there, so one launch replaces the
-// partial-sum and reduce launches of the split-K form and writes no fp32 intermediates.
+// At most 4 token rows (a decode step of up to four samples): a GEMV-shaped kernel with no split-K and no partial
+// sums.  A wave owns NF weight rows over the WHOLE reduction; its 64 lanes split K in 16-byte pieces, so every load
+// instruction reads 1 KiB that is contiguous in memory (the weight row itself), ST - 1 steps in flight behind the one
+// being multiplied.  The few activation rows are staged once per workgroup in LDS (its four waves share the copy),
+// optionally RMS-normalised on the way (NORM: Qwen2RMSNorm, modeling_qwen2.py:54-59: x_n = w * bf16(x * rs),
+// rs = rsqrt(mean(x^2) + eps)), while the first weight stages are already in flight; registers then hold weights
+// only, and a wave's own instruction chain stays short - a projection of a decode step has two or three waves per
+// SIMD, so whatever a wave computes besides the products is exposed.
+// v_dot2c_f32_bf16 accumulates in fp32 per lane; the lanes' sums are combined by a butterfly that halves the number of
+// live values at every exchange, after which lane (64 / V) v holds output value v.  Bias / SiLU / residual / SwiGLU
+// are applied there, so one launch replaces the partial-sum and reduce launches of the split-K form (and the launch
+// of a separate normalisation kernel) and writes no fp32 intermediates.
 // Values are numbered v = m * NF + f (row m, weight row f of the wave).  With SwiGLU the wave's NF weight rows
 // are NF/2 (gate, up) pairs: rows f and f + 16 of the [16 gate | 16 up] interleave.
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
-// NORM: the rows of X are RMS-normalised on the way in (Qwen2RMSNorm, modeling_qwen2.py:54-59: x_n = w * bf16(x * rs),
-// rs = rsqrt(mean(x^2) + eps)), with the same lane / element assignment and summation order as rmsnorm_kernel.  Every
-// wave recomputes the few rows' statistics from L1 / L2 (K * 2 bytes per row), which costs less than the launch and
-// the round trip of a separate normalisation kernel.
+// One butterfly level over lane ^ WD with NL live values in val[0 .. NL): NL > 1 halves them (a lane keeps the values
+// whose index bit equals its own lane bit and receives the partner's copies), NL == 1 is a plain sum.  Either way
+// val[i] = own + partner's on the same operands.
+template <int WD, int NL, int V>
+__device__ __forceinline__ void bfly_level(float (&val)[V], int lane) {
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_;
+  constexpr int PAIRS = NL > 1 ? NL / 2 : 1;
+  constexpr int OFF = NL > 1 ? NL / 2 : 0;
+  const bool upper = (lane & WD) != 0;
+#pragma unroll
+  for (int i = 0; i < PAIRS; ++i) {
+    const float a = val[i], b = val[i + OFF];
+    if constexpr (WD == 32) {
+      const u32x2_ r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+      val[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else if constexpr (WD == 16) {
+      const u32x2_ r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+      val[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else {
+      const float keep = upper ? b : a, give = upper ? a : b;
+      val[i] = keep + xor_lane<WD>(give);
+    }
+  }
+}
+
 template <int NF, int MR, int ST, bool NORM>
-__global__ __launch_bounds__(256) void gemv_rows_kernel(const bf16* __restrict__ X, long ldx, const bf16* __restrict__ W,
-                                                        long ldw, bf16* __restrict__ C, long ldc, int M, int N, int K,
-                                                        const bf16* __restrict__ bias, const bf16* __restrict__ R,
-                                                        long ldr, int epilogue, const bf16* __restrict__ norm_w,
-                                                        float eps) {
+__global__ __launch_bounds__(1024) void gemv_rows_kernel(const bf16* __restrict__ X, long ldx, const bf16* __restrict__ W,
+                                                         long ldw, bf16* __restrict__ C, long ldc, int M, int N, int K,
+                                                         const bf16* __restrict__ bias, const bf16* __restrict__ R,
+                                                         long ldr, int epilogue, const bf16* __restrict__ norm_w,
+                                                         float eps) {
   constexpr int V = NF * MR;              // values per wave, a power of two <= 32
   static_assert((V & (V - 1)) == 0 && V <= 32, "NF * MR must be a power of two, at most 32");
-  const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nthreads = blockDim.x, nwaves = nthreads >> 6;   // the launcher picks the workgroup size (4 to 16 waves)
+  const int wave = blockIdx.x * nwaves + (tid >> 6);
   const bool swiglu = epilogue == SK_SWIGLU;
   // weight rows of this wave
   int wrow[NF];
@@ -195,13 +223,11 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const bf16* __restrict__
 #pragma unroll
     for (int f = 0; f < NF; ++f) wrow[f] = wave * NF + f;
   }
-  if (wrow[0] >= N) return;               // whole wave out of range (N is a multiple of NF / of 32 with SwiGLU)
+  // a wave whose rows are all out of range (N is a multiple of NF / of 32 with SwiGLU) still helps to stage the rows
+  const bool live = wrow[0] < N;
   const bf16* wp[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) wp[f] = W + (long)min(wrow[f], N - 1) * ldw + lane * 8;
-  const bf16* xp[MR];
-#pragma unroll
-  for (int m = 0; m < MR; ++m) xp[m] = X + (long)min(m, M - 1) * ldx + lane * 8;
 
   float acc[MR][NF];
 #pragma unroll
@@ -210,83 +236,104 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const bf16* __restrict__
     for (int f = 0; f < NF; ++f) acc[m][f] = 0.f;
 
   const int nsteps = K / 512;             // K % 512 == 0 is checked by the launcher
-  float rs[MR];
+  extern __shared__ __attribute__((aligned(16))) bf16 xs[];   // the (normalised) activation rows [MR][K]
+  __shared__ float rs_s[MR];
   // ST register stages: the loads of the next ST - 1 steps are in flight behind the step being multiplied
-  bf16x8 wf[ST][NF], xf[ST][MR], nf[ST];
+  bf16x8 wf[ST][NF];
   auto load = [&](int st, int step) {
-#pragma unroll
     // non-temporal: every weight byte is read once by one wave; measured 5-15 % faster than the default policy on
     // this kernel (decode step 3.15 against 3.30-3.46 ms per token, the vocabulary projection 6.7 against 5.8 TB/s)
+#pragma unroll
 #ifndef BAGEL_GEMV_DEFAULT_POLICY
     for (int f = 0; f < NF; ++f) wf[st][f] = __builtin_nontemporal_load((const bf16x8*)(wp[f] + step * 512));
 #else
     for (int f = 0; f < NF; ++f) wf[st][f] = *(const bf16x8*)(wp[f] + step * 512);
 #endif
-#pragma unroll
-    for (int m = 0; m < MR; ++m) xf[st][m] = *(const bf16x8*)(xp[m] + step * 512);
-    if constexpr (NORM) nf[st] = *(const bf16x8*)(norm_w + lane * 8 + step * 512);
   };
-  auto compute = [&](int st) {
-    if constexpr (NORM) {
+  auto compute = [&](int st, int cstep) {   // cstep: the step's index along K
 #pragma unroll
-      for (int m = 0; m < MR; ++m)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xf[st][m][j] = (bf16)((float)nf[st][j] * round_bf16((float)xf[st][m][j] * rs[m]));
-    }
-#pragma unroll
-    for (int m = 0; m < MR; ++m)
+    for (int m = 0; m < MR; ++m) {
+      const bf16x8 x = *(const bf16x8*)(xs + (long)m * K + cstep * 512 + lane * 8);
 #pragma unroll
       for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           acc[m][f] = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{wf[st][f][2 * e], wf[st][f][2 * e + 1]},
-                                                      bf16x2_t{xf[st][m][2 * e], xf[st][m][2 * e + 1]}, acc[m][f], false);
+                                                      bf16x2_t{x[2 * e], x[2 * e + 1]}, acc[m][f], false);
+    }
   };
-#pragma unroll
-  for (int j = 0; j < ST - 1; ++j)
-    if (j < nsteps) load(j, j);
-  if constexpr (NORM) {
-    // row statistics, computed with the first weight stages already in flight (the activations come from L2)
+  // the workgroup's threads stage the rows in LDS
+  auto stage = [&]() {
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
+      const bf16* xr = X + (long)min(m, M - 1) * ldx;
+      for (int e0 = tid * 8; e0 < K; e0 += nthreads * 8) {
+        bf16x8 v = *(const bf16x8*)(xr + e0);
+        if constexpr (NORM) {
+          const bf16x8 nw = *(const bf16x8*)(norm_w + e0);
+          const float rsm = rs_s[m];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)nw[j] * round_bf16((float)v[j] * rsm));
+        }
+        *(bf16x8*)(xs + (long)m * K + e0) = v;
+      }
+    }
+  };
+  if (live) {   // the first weight stages are in flight while the rows are staged
+#pragma unroll
+    for (int j = 0; j < ST - 1; ++j)
+      if (j < nsteps) load(j, j);
+  }
+  if constexpr (NORM) {
+    __shared__ float red[MR][16];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const bf16* xr = X + (long)min(m, M - 1) * ldx;
       float ss = 0.f;
-      for (int step = 0; step < nsteps; ++step) {
-        const bf16x8 v = *(const bf16x8*)(xp[m] + step * 512);
+      for (int e0 = tid * 8; e0 < K; e0 += nthreads * 8) {
+        const bf16x8 v = *(const bf16x8*)(xr + e0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) ss += (float)v[j] * (float)v[j];
       }
-      rs[m] = rsqrtf(wave_sum(ss) / (float)K + eps);
+      ss = wave_sum(ss);
+      if (lane == 0) red[m][tid >> 6] = ss;
     }
+    __syncthreads();
+    if (tid < MR) {
+      float tot = 0.f;
+      for (int w = 0; w < nwaves; ++w) tot += red[tid][w];
+      rs_s[tid] = rsqrtf(tot / (float)K + eps);
+    }
+    __syncthreads();
   }
+  stage();
+  __syncthreads();
+  if (!live) return;
   for (int step = 0; step < nsteps; step += ST) {
 #pragma unroll
     for (int j = 0; j < ST; ++j) {
       if (step + j + ST - 1 < nsteps) load((j + ST - 1) % ST, step + j + ST - 1);
-      if (step + j < nsteps) compute(j);
+      if (step + j < nsteps) compute(j, step + j);
     }
   }
 
-  // butterfly: after the exchange with lane ^ 32 a lane keeps the values whose top index bit equals its own bit 5,
-  // and so on down to one value per group of (64 / V) lanes, which the last exchanges sum completely
+  // Butterfly over lane ^ 32, 16, 8, 4, 2, 1, always in that order: while more than one value is live an exchange
+  // halves their number (a lane keeps the values whose index bit equals its own lane bit and receives the partner's
+  // copies of them), afterwards a plain sum.  Either way a level computes own + partner on the same operands, so a
+  // row's result does not depend on how many rows (MR) the launch carries.  The levels over 32 and 16 lanes are the
+  // gfx950 lane swaps (the sum of a swap's two results is own + partner on every lane).
   float val[V];
 #pragma unroll
   for (int m = 0; m < MR; ++m)
 #pragma unroll
     for (int f = 0; f < NF; ++f) val[m * NF + f] = acc[m][f];
-  int width = 32;
-#pragma unroll
-  for (int n = V; n > 1; n >>= 1, width >>= 1) {
-    const bool upper = (lane & width) != 0;
-#pragma unroll
-    for (int i = 0; i < n / 2; ++i) {
-      const float keep = upper ? val[i + n / 2] : val[i];
-      const float give = upper ? val[i] : val[i + n / 2];
-      val[i] = keep + __shfl_xor(give, width, 64);
-    }
-  }
-  float total = val[0];
-#pragma unroll
-  for (; width >= 1; width >>= 1) total += __shfl_xor(total, width, 64);
+  bfly_level<32, V, V>(val, lane);
+  bfly_level<16, (V / 2 > 1 ? V / 2 : 1), V>(val, lane);
+  bfly_level<8, (V / 4 > 1 ? V / 4 : 1), V>(val, lane);
+  bfly_level<4, (V / 8 > 1 ? V / 8 : 1), V>(val, lane);
+  bfly_level<2, (V / 16 > 1 ? V / 16 : 1), V>(val, lane);
+  bfly_level<1, (V / 32 > 1 ? V / 32 : 1), V>(val, lane);
+  const float total = val[0];
   // every lane of a group of 64 / V lanes now holds the total of value v = lane / (64 / V)
   constexpr int GROUP = 64 / V;
   const int v = lane / GROUP, m = v / NF, f = v % NF;
@@ -309,33 +356,65 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const bf16* __restrict__
   C[(long)m * ldc + n] = (bf16)a;
 }
 
+constexpr long GEMV_LDS = 96 * 1024;   // staged activation rows per workgroup
+
+static int gemv_rows_template(int M) { return M <= 1 ? 1 : M <= 2 ? 2 : 4; }
+
 static bool gemv_eligible(int M, int N, int K, int epilogue) {
   if (K % 512 != 0 || N % 4 != 0 || (epilogue == SK_SWIGLU && N % 32 != 0)) return false;
-  // measured on MI355X against the split-K form (tools/skinny_bench.py): ahead at one or two rows for every shape
-  // (15 % per layer), at three or four rows only for the narrow projections
+  if ((long)gemv_rows_template(M) * K * 2 > GEMV_LDS) return false;   // the staged rows must fit LDS
+  // measured on MI355X against the split-K form (tools/skinny_bench.py): ahead at one or two rows for every shape,
+  // at three or four rows only for the narrow projections; beyond that the dot-product instruction is the bound
+  // (eight rows: 2.3 TB/s) and the MFMA form wins
   return M <= 2 || (M <= 4 && epilogue != SK_SWIGLU && N <= 16384);
 }
 
 static int g_skinny_gemv = 1;   // development knob: 0 forces the split-K form (bagel_set_skinny_gemv)
 extern "C" void bagel_set_skinny_gemv(int on) { g_skinny_gemv = on; }
 
+// Waves per workgroup for launches whose workgroups are all resident at once: they are spread evenly over the CUs, so
+// the launch lasts as long as the CU with the most waves.  3584 rows in workgroups of four 2-row waves are 448
+// workgroups: 192 CUs stream two of them and 64 CUs one.  In workgroups of seven waves they are one per CU.
+static int gemv_waves_per_block(long waves) {
+  const long cus = bagel_cu_count();
+  if (waves > 16 * cus) return 4;
+  int best = 4;
+  long best_span = -1;
+  for (int wpb = 4; wpb <= 16; ++wpb) {
+    const long blocks = (waves + wpb - 1) / wpb;
+    const long span = (blocks + cus - 1) / cus * wpb;
+    if (best_span < 0 || span < best_span) {
+      best_span = span;
+      best = wpb;
+    }
+  }
+  return best;
+}
+
+template <int NF, int MR, int ST, bool NORM>
+static void gemv_launch_one(const bf16* X, long ldx, const bf16* W, long ldw, bf16* C, long ldc, int M, int N, int K,
+                            const bf16* bias, const bf16* R, long ldr, int epilogue, const bf16* norm_w, float eps,
+                            hipStream_t st) {
+  const int waves = N / NF, wpb = gemv_waves_per_block(waves);
+  static BagelLdsAllowed allowed;
+  bagel_allow_lds(allowed, (const void*)gemv_rows_kernel<NF, MR, ST, NORM>, (int)GEMV_LDS);
+  hipLaunchKernelGGL((gemv_rows_kernel<NF, MR, ST, NORM>), dim3((waves + wpb - 1) / wpb), dim3(64 * wpb), (size_t)MR * K * 2, st,
+                     X, ldx, W, ldw, C, ldc, M, N, K, bias, R, ldr, epilogue, norm_w, eps);
+}
+
 static void gemv_launch(const bf16* X, long ldx, const bf16* W, long ldw, bf16* C, long ldc, int M, int N, int K,
                         const bf16* bias, const bf16* R, long ldr, int epilogue, const bf16* norm_w, float eps,
                         hipStream_t st) {
-  // NF weight rows per wave: enough of them that the activation rows (re-read by every wave, from L1 / L2) stay a
-  // small multiple of the weight bytes on the load path
-#define GEMV(NF, MR, ST, NORM)                                                                                        \
-  hipLaunchKernelGGL((gemv_rows_kernel<NF, MR, ST, NORM>), dim3((N / NF + 3) / 4), dim3(256), 0, st, X, ldx, W, ldw, C,   \
-                     ldc, M, N, K, bias, R, ldr, epilogue, norm_w, eps)
-  // (one weight row per wave, i.e. twice the waves, measured no faster on the narrow projections)
-  if (norm_w) {
-    if (M <= 1) GEMV(2, 1, 4, true);
-    else if (M <= 2) GEMV(2, 2, 4, true);
-    else GEMV(2, 4, 2, true);
-  } else {
-    if (M <= 1) GEMV(2, 1, 4, false);
-    else if (M <= 2) GEMV(2, 2, 4, false);
-    else GEMV(2, 4, 2, false);
+  // Two weight rows per wave.  A projection with few waves per CU (everything but gate+up and the vocabulary) needs
+  // more steps in flight per wave to keep ~64 KB per CU outstanding: eight stages there, four otherwise.
+  const bool deep = (long)N / 2 < 16L * bagel_cu_count();
+#define GEMV(MR, ST)                                                                                                          \
+  (norm_w ? gemv_launch_one<2, MR, ST, true>(X, ldx, W, ldw, C, ldc, M, N, K, bias, R, ldr, epilogue, norm_w, eps, st)        \
+          : gemv_launch_one<2, MR, ST, false>(X, ldx, W, ldw, C, ldc, M, N, K, bias, R, ldr, epilogue, norm_w, eps, st))
+  switch (gemv_rows_template(M)) {
+    case 1: deep ? GEMV(1, 8) : GEMV(1, 4); break;
+    case 2: deep ? GEMV(2, 8) : GEMV(2, 4); break;
+    default: deep ? GEMV(4, 8) : GEMV(4, 4); break;
   }
 #undef GEMV
 }
