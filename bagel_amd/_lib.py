@@ -297,7 +297,7 @@ class MotRows(ctypes.Structure):
     _fields_ = [("rows_gen", I), ("rows_und", I), ("X", VP), ("Xn", VP), ("QKV", VP), ("Q", VP), ("O", VP), ("Hm", VP),
                 ("cos_table", VP), ("sin_table", VP), ("row_cs", VP), ("row_slot", VP), ("tiles", VP), ("n_tiles", I),
                 ("S", L), ("skinny_ws", VP), ("skinny_ws_bytes", L), ("und_rounding", I),
-                ("decode_ws", VP), ("decode_ws_bytes", L)]
+                ("decode_ws", VP), ("decode_ws_bytes", L), ("decode_max_kv", L)]
 
 
 def _addr(t):
@@ -305,13 +305,13 @@ def _addr(t):
 
 
 def mot_rows(rows_gen, rows_und, X, Xn, QKV, Q, O, Hm, cos_t, sin_t, row_cs, row_slot, tiles, n_tiles, S, skinny_ws,
-             und_rounding=False, decode_ws=None) -> MotRows:
+             und_rounding=False, decode_ws=None, decode_max_kv=0) -> MotRows:
     """The per-forward argument block of mot_forward; the tensors must outlive the call.  decode_ws (zeroed once by the
     caller, decode_attention_workspace_bytes) lets a decode step run its attention in one launch."""
     return MotRows(rows_gen, rows_und, _addr(X), _addr(Xn), _addr(QKV), _addr(Q), _addr(O), _addr(Hm), _addr(cos_t),
                    _addr(sin_t), _addr(row_cs), _addr(row_slot), _addr(tiles), n_tiles, S, _addr(skinny_ws),
                    skinny_ws.numel() * skinny_ws.element_size(), 1 if und_rounding else 0, _addr(decode_ws),
-                   0 if decode_ws is None else decode_ws.numel() * decode_ws.element_size())
+                   0 if decode_ws is None else decode_ws.numel() * decode_ws.element_size(), decode_max_kv)
 
 
 def decode_attention_supported(rows, Hq, Hkv, D) -> bool:
@@ -323,11 +323,11 @@ def decode_attention_workspace_bytes(rows, Hq, Hkv, D) -> int:
 
 
 def decode_attention(qkv, Hq, Hkv, D, q_norm, k_norm, cos_t, sin_t, row_cs, row_slot, tiles, K_ws, Vt_ws, S, O, eps,
-                     und_rounding, workspace):
+                     und_rounding, workspace, max_kv_len=0):
     """One new token per row: q/k norm + RoPE, KV write and attention in one launch (bagel_decode_attention_bf16)."""
     _check(lib().bagel_decode_attention_bf16(_p(qkv), L(qkv.stride(0)), I(qkv.shape[0]), I(Hq), I(Hkv), I(D), _p(q_norm),
                                              _p(k_norm), _p(cos_t), _p(sin_t), _p(row_cs), _p(row_slot), _p(tiles), _p(K_ws),
-                                             _p(Vt_ws), L(S), _p(O), F(eps), I(1 if und_rounding else 0), _p(workspace),
+                                             _p(Vt_ws), L(S), _p(O), F(eps), I(1 if und_rounding else 0), L(max_kv_len), _p(workspace),
                                              L(workspace.numel() * workspace.element_size()), _stream()),
            "bagel_decode_attention_bf16")
 

@@ -321,7 +321,7 @@ extern "C" int bagel_decode_attention_bf16(const void* qkv, long ld, int rows, i
                                            const void* q_norm, const void* k_norm, const void* cos_table,
                                            const void* sin_table, const void* row_cs, const void* row_slot,
                                            const void* tiles, void* K_ws, void* Vt_ws, long S, void* O, float eps,
-                                           int und_rounding, void* workspace, long workspace_bytes, void* stream) {
+                                           int und_rounding, long max_kv_len, void* workspace, long workspace_bytes, void* stream) {
   BAGEL_CHECK(qkv && q_norm && k_norm && cos_table && sin_table && row_cs && row_slot && tiles && K_ws && Vt_ws && O && workspace,
               "bagel_decode_attention_bf16: null operand");
   BAGEL_CHECK(bagel_decode_attention_supported(rows, Hq, Hkv, head_dim),
@@ -342,9 +342,11 @@ extern "C" int bagel_decode_attention_bf16(const void* qkv, long ld, int rows, i
   p.tickets = (unsigned*)workspace; p.part = (float*)((char*)workspace + 256);
   p.S = S; p.Hq = Hq; p.Hkv = Hkv; p.eps = eps; p.und_rounding = und_rounding;
   p.scale_log2 = 1.4426950408889634f / sqrtf((float)head_dim);
-  // no sample has more keys than the workspace has slots, which bounds the chunks any of them can use
+  // no sample has more keys than the caller's bound (or than the workspace has slots), which bounds the chunks any of
+  // them can use: workgroups beyond a sample's chunks exit at once, but a thousand of them still cost a launch each
   p.min_chunk = g_decode_min_chunk;
-  const int splits = (int)std::min<long>(MAX_SPLITS, (S + p.min_chunk - 1) / p.min_chunk);
+  const long kv_bound = max_kv_len > 0 ? std::min(max_kv_len, S) : S;
+  const int splits = (int)std::min<long>(MAX_SPLITS, (kv_bound + p.min_chunk - 1) / p.min_chunk);
   const dim3 grid(splits, Hkv, rows), block(1024);
   const int rep = Hq / Hkv;
   hipStream_t st = (hipStream_t)stream;

@@ -102,7 +102,7 @@ extern "C" int bagel_mot_layer_forward(const bagel_mot_dims* d, const bagel_mot_
     if (one_launch) {
       BAGEL_CHECK(r->O && r->Hm && r->tiles, "bagel_mot_layer_forward: null attention / MLP buffer");
       TRY(bagel_decode_attention_bf16(r->QKV, qkv, M, Hq, Hkv, D, u.q_norm, u.k_norm, r->cos_table, r->sin_table, r->row_cs,
-                                      r->row_slot, r->tiles, K_ws, Vt_ws, r->S, r->O, eps, r->und_rounding, r->decode_ws,
+                                      r->row_slot, r->tiles, K_ws, Vt_ws, r->S, r->O, eps, r->und_rounding, r->decode_max_kv, r->decode_ws,
                                       r->decode_ws_bytes, stream));
     } else {
       TRY(bagel_qk_norm_rope_kv_bf16(r->QKV, qkv, M, Hq, Hkv, D, u.q_norm, u.q_norm, u.k_norm, u.k_norm, M, r->cos_table,
@@ -123,11 +123,21 @@ extern "C" int bagel_mot_layer_forward(const bagel_mot_dims* d, const bagel_mot_
   if (!(flags & BAGEL_LAYER_XN_READY)) TRY(bagel_rmsnorm_bf16(r->X, H, r->Xn, H, M, H, ln_in_a, u.ln_in, split, eps, stream));
   if (Mv) TRY(bagel_gemm_bf16(r->Xn, H, g.wqkv, H, r->QKV, qkv, Mv, qkv, H, g.bqkv, nullptr, 0, BAGEL_EPI_BIAS, 1.0f, stream));
   if (Mt) TRY(und_linear(Xn_u, H, u.wqkv, at(r->QKV, Mv, qkv), qkv, Mt, qkv, H, u.bqkv, nullptr, 0, 0, r, stream));
-  TRY(bagel_qk_norm_rope_kv_bf16(r->QKV, qkv, M, Hq, Hkv, D, qn_a, u.q_norm, kn_a, u.k_norm, split, r->cos_table, r->sin_table,
-                                 r->row_cs, r->row_slot, r->Q, K_ws, Vt_ws, r->S, eps, r->und_rounding, stream));
-  if (flags & BAGEL_LAYER_KV_ONLY) return 0;
-  BAGEL_CHECK(r->O && r->Hm && r->tiles && r->n_tiles > 0, "bagel_mot_layer_forward: null attention / MLP buffer");
-  TRY(bagel_varlen_attention_bf16(r->Q, K_ws, Vt_ws, r->O, r->tiles, r->n_tiles, Hq, Hkv, D, r->S, stream));
+  // a decode step of more than four samples (the caller's decode workspace says every row is one sample's new token)
+  const bool decode_rows = Mv == 0 && r->decode_ws && !(flags & BAGEL_LAYER_KV_ONLY) && r->n_tiles == M &&
+                           bagel_decode_attention_supported(M, Hq, Hkv, D);
+  if (decode_rows) {
+    BAGEL_CHECK(r->O && r->Hm && r->tiles, "bagel_mot_layer_forward: null attention / MLP buffer");
+    TRY(bagel_decode_attention_bf16(r->QKV, qkv, M, Hq, Hkv, D, u.q_norm, u.k_norm, r->cos_table, r->sin_table, r->row_cs,
+                                    r->row_slot, r->tiles, K_ws, Vt_ws, r->S, r->O, eps, r->und_rounding, r->decode_max_kv, r->decode_ws,
+                                    r->decode_ws_bytes, stream));
+  } else {
+    TRY(bagel_qk_norm_rope_kv_bf16(r->QKV, qkv, M, Hq, Hkv, D, qn_a, u.q_norm, kn_a, u.k_norm, split, r->cos_table, r->sin_table,
+                                   r->row_cs, r->row_slot, r->Q, K_ws, Vt_ws, r->S, eps, r->und_rounding, stream));
+    if (flags & BAGEL_LAYER_KV_ONLY) return 0;
+    BAGEL_CHECK(r->O && r->Hm && r->tiles && r->n_tiles > 0, "bagel_mot_layer_forward: null attention / MLP buffer");
+    TRY(bagel_varlen_attention_bf16(r->Q, K_ws, Vt_ws, r->O, r->tiles, r->n_tiles, Hq, Hkv, D, r->S, stream));
+  }
   if (Mv) TRY(bagel_gemm_bf16(r->O, qd, g.wo, qd, r->X, H, Mv, H, qd, nullptr, r->X, H, BAGEL_EPI_RESIDUAL, 1.0f, stream));
   if (fuse_norm) {
     TRY(bagel_skinny_gemm_residual_rmsnorm_bf16(r->O, qd, u.wo, qd, r->X, H, Mt, H, qd, r->X, H, u.ln_post, r->Xn, H, eps,

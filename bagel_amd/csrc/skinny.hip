@@ -369,6 +369,167 @@ static bool gemv_eligible(int M, int N, int K, int epilogue) {
   return M <= 2 || (M <= 4 && epilogue != SK_SWIGLU && N <= 16384);
 }
 
+// ---------------------------------------------------------------------------------------------
+// One-launch MFMA form for any row count up to 64: the split-K idea with the K slices inside ONE workgroup.
+// A workgroup owns RB blocks of 16 weight rows (with SwiGLU: gate blocks and their up blocks alternate; the token-row
+// fragments are loaded once per step for all RB blocks); its waves take
+// the 128-deep K steps round-robin (slice q: steps q, q + ns, ...) with the split-K kernel's operand layout and two
+// register stages, leave their fp32 accumulators in LDS, and waves 0 .. G-1 add them in slice order and apply the
+// epilogue.  No partial sums in memory, no second launch.  The K split depends only on (N, K), and a row's products
+// never meet another row's, so a row's result does not depend on how many rows share the launch.
+// ---------------------------------------------------------------------------------------------
+template <int G, int RB, int MAXT>
+__global__ __launch_bounds__(MAXT) void stream_mfma_kernel(const bf16* __restrict__ X, long ldx, const bf16* __restrict__ W,
+                                                           long ldw, bf16* __restrict__ C, long ldc, int M, int N, int K,
+                                                           const bf16* __restrict__ bias, const bf16* __restrict__ R,
+                                                           long ldr, int epilogue, int ns) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 red_s[];   // [ns][RB][G][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+  const int r = lane & 15, h = lane >> 4;
+  const int row0 = blockIdx.x * (16 * RB);
+  const int nsteps = K / 128;
+  const bf16* wp[RB];
+#pragma unroll
+  for (int b = 0; b < RB; ++b) wp[b] = W + (long)(row0 + b * 16 + r) * ldw + h * 8;
+  const bf16* xp[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) xp[g] = X + (long)min(g * 16 + r, M - 1) * ldx + h * 8;
+  f32x4 acc[RB][G];
+  bf16x8 wf[2][RB][4], xf[2][G][4];
+  auto load = [&](int st, int step) {
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[st][b][j] = *(const bf16x8*)(wp[b] + step * 128 + j * 32);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf[st][g][j] = *(const bf16x8*)(xp[g] + step * 128 + j * 32);
+  };
+  auto compute = [&](int st) {
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[b][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[st][b][j], xf[st][g][j], acc[b][g], 0, 0, 0);
+  };
+  // K slice q is steps q, q + ns, ...; a wave takes slices wave, wave + nw, ... (one each unless the register budget
+  // of many token rows limits the workgroup to fewer waves than slices)
+  for (int q = wave; q < ns; q += nw) {
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+      for (int g = 0; g < G; ++g) acc[b][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (q < nsteps) load(0, q);
+    for (int s = q; s < nsteps; s += 2 * ns) {
+      if (s + ns < nsteps) load(1, s + ns);
+      compute(0);
+      if (s + 2 * ns < nsteps) load(0, s + 2 * ns);
+      if (s + ns < nsteps) compute(1);
+    }
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+      for (int g = 0; g < G; ++g) red_s[((q * RB + b) * G + g) * 64 + lane] = acc[b][g];
+  }
+  __syncthreads();
+  if (wave >= G) return;
+  // wave g finishes row group g: lane (r, h) holds features row0 + 4h .. 4h + 3 of token row m = 16 g + r
+  const int m = wave * 16 + r;
+  f32x4 v[RB];
+#pragma unroll
+  for (int b = 0; b < RB; ++b) {
+    v[b] = red_s[(b * G + wave) * 64 + lane];
+    for (int q = 1; q < ns; ++q) v[b] += red_s[((q * RB + b) * G + wave) * 64 + lane];
+  }
+  if (m >= M) return;
+  bf16x4 out;
+  if (epilogue == SK_SWIGLU) {   // even blocks hold the gate rows, odd blocks the up rows of the same 16 features
+    if constexpr (RB >= 2) {
+#pragma unroll
+      for (int pr = 0; pr < RB / 2; ++pr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          out[i] = (bf16)(round_bf16(silu_f32(round_bf16(v[2 * pr][i]))) * round_bf16(v[2 * pr + 1][i]));
+        *(bf16x4*)(C + (long)m * ldc + (blockIdx.x * (RB / 2) + pr) * 16 + h * 4) = out;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int b = 0; b < RB; ++b) {
+    const int n = row0 + b * 16 + h * 4;
+    bf16x4 rv = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    if (epilogue == SK_RESIDUAL) rv = *(const bf16x4*)(R + (long)m * ldr + n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a = v[b][i];
+      if (bias) a += (float)bias[n + i];
+      if (epilogue == SK_RESIDUAL) a = round_bf16(a) + (float)rv[i];
+      if (epilogue == SK_BIAS_SILU) a = silu_f32(round_bf16(a));
+      out[i] = (bf16)a;
+    }
+    *(bf16x4*)(C + (long)m * ldc + n) = out;
+  }
+}
+
+// Waves per workgroup: enough waves on the chip (about 24 per CU when the shape allows) and K steps that divide evenly.
+static int stream_waves_per_block(int blocks, int ksteps, int max_nw) {
+  const long want = 24L * bagel_cu_count();
+  int ideal = (int)std::min<long>(max_nw, std::max<long>(2, (want + blocks - 1) / blocks));
+  ideal = std::min(ideal, ksteps);
+  int best = ideal;
+  double best_score = -1.0;
+  for (int nw = std::max(1, ideal / 2); nw <= std::min({max_nw, ksteps, 2 * ideal}); ++nw) {
+    const int per = (ksteps + nw - 1) / nw;
+    const double balance = (double)ksteps / ((double)per * nw);              // 1.0: every wave has the same steps
+    const double close = 1.0 - 0.1 * std::abs(nw - ideal) / (double)ideal;   // mild preference for the ideal count
+    if (balance * close > best_score) {
+      best_score = balance * close;
+      best = nw;
+    }
+  }
+  return best;
+}
+
+static int g_stream_mfma = 1;   // development knob: 0 keeps the split-K form (bagel_set_stream_mfma)
+extern "C" void bagel_set_stream_mfma(int on) { g_stream_mfma = on; }
+
+template <int G, int RB, int MAXT>
+static void stream_launch_one(const bf16* X, long ldx, const bf16* W, long ldw, bf16* C, long ldc, int M, int N, int K,
+                              const bf16* bias, const bf16* R, long ldr, int epilogue, int ns, hipStream_t st) {
+  const int blocks = N / (16 * RB);
+  // one wave per K slice where the workgroup may have that many; at least G waves: wave g finishes row group g
+  const int nw = std::max(G, std::min(ns, MAXT / 64));
+  hipLaunchKernelGGL((stream_mfma_kernel<G, RB, MAXT>), dim3(blocks), dim3(64 * nw), (size_t)ns * RB * G * 1024, st, X, ldx, W,
+                     ldw, C, ldc, M, N, K, bias, R, ldr, epilogue, ns);
+}
+
+// Row blocks per workgroup: one (two with SwiGLU), except for very wide projections (the vocabulary) at more than 8
+// token rows, where four blocks share every load of the token-row fragments - as many bytes per step as a weight
+// block once there are 16 rows (222 against 268 us at 16 rows; the same on gate+up, 592 workgroups, loses 14 %).
+// More than 16 rows need 256 registers: 512-thread workgroups.
+static void stream_launch(const bf16* X, long ldx, const bf16* W, long ldw, bf16* C, long ldc, int M, int N, int K,
+                          const bf16* bias, const bf16* R, long ldr, int epilogue, hipStream_t st) {
+  const int G = (M + 15) / 16;
+  const bool sw = epilogue == SK_SWIGLU;
+  // K slices: a function of the projection alone (never of the row count), so that a row's fp32 sums keep their
+  // order whatever shares the launch.  Their accumulators meet in LDS: ns * RB * G KiB <= 64 KiB.
+  const int rb = sw ? 2 : 1;
+  const int ns = stream_waves_per_block(N / (16 * rb), K / 128, 16 / rb);
+  const bool wide = M > 8 && !sw && N % 64 == 0 && N / 64 >= 8 * bagel_cu_count() && ns * 4 * G <= 64;
+#define STREAM(G_, RB_, MAXT_) stream_launch_one<G_, RB_, MAXT_>(X, ldx, W, ldw, C, ldc, M, N, K, bias, R, ldr, epilogue, ns, st)
+  switch (G) {
+    case 1: wide ? STREAM(1, 4, 512) : sw ? STREAM(1, 2, 1024) : STREAM(1, 1, 1024); break;
+    case 2: wide ? STREAM(2, 4, 512) : sw ? STREAM(2, 2, 512) : STREAM(2, 1, 1024); break;
+    case 3: sw ? STREAM(3, 2, 512) : STREAM(3, 1, 512); break;
+    default: sw ? STREAM(4, 2, 512) : STREAM(4, 1, 512); break;
+  }
+#undef STREAM
+}
+
 static int g_skinny_gemv = 1;   // development knob: 0 forces the split-K form (bagel_set_skinny_gemv)
 extern "C" void bagel_set_skinny_gemv(int on) { g_skinny_gemv = on; }
 
@@ -438,6 +599,13 @@ static int skinny_launch(const void* X, long ldx, const void* W, long ldw, void*
   if (allow_gemv && g_skinny_gemv && !norm_weight && gemv_eligible(M, N, K, epilogue)) {
     gemv_launch((const bf16*)X, ldx, (const bf16*)W, ldw, (bf16*)C, ldc, M, N, K, (const bf16*)bias, (const bf16*)residual, ldr,
                 epilogue, nullptr, 0.f, (hipStream_t)stream);
+    BAGEL_LAUNCH_CHECK();
+    return 0;
+  }
+  if (g_stream_mfma && !norm_weight && ldc % 4 == 0 && (epilogue != SK_RESIDUAL || ldr % 4 == 0) &&
+      ((uintptr_t)C | (uintptr_t)residual) % 8 == 0) {
+    stream_launch((const bf16*)X, ldx, (const bf16*)W, ldw, (bf16*)C, ldc, M, N, K, (const bf16*)bias, (const bf16*)residual, ldr,
+                  epilogue, (hipStream_t)stream);
     BAGEL_LAUNCH_CHECK();
     return 0;
   }
@@ -526,6 +694,14 @@ extern "C" int bagel_skinny_gemm_residual_rmsnorm_bf16(const void* X, long ldx, 
                                                        const void* norm_weight, void* Xn, long ldn, float eps,
                                                        void* workspace, long workspace_bytes, void* stream) {
   BAGEL_CHECK(norm_weight && Xn && ldn >= N, "bagel_skinny_gemm_residual_rmsnorm_bf16: null norm operand");
+  if (g_stream_mfma) {
+    // the one-launch projection leaves the finished rows in C; their norm is one small launch more, the same two
+    // launches as partial sums + (reduce, residual, norm), with the faster projection
+    if (int rc = skinny_launch(X, ldx, W, ldw, C, ldc, M, N, K, nullptr, residual, ldr, SK_RESIDUAL, workspace, workspace_bytes,
+                               nullptr, nullptr, 0, 0.f, false, stream))
+      return rc;
+    return bagel_rmsnorm_bf16(C, ldc, Xn, ldn, M, N, norm_weight, norm_weight, M, eps, stream);
+  }
   return skinny_launch(X, ldx, W, ldw, C, ldc, M, N, K, nullptr, residual, ldr, SK_RESIDUAL, workspace, workspace_bytes,
                        norm_weight, Xn, ldn, eps, false, stream);
 }

@@ -166,10 +166,11 @@ typedef struct bagel_mot_rows {        /* one packed forward: activations, table
   void* skinny_ws;                     /* fp32 split-K partials: bagel_skinny_gemm_workspace_bytes(min(rows_und, 64), 2I) */
   long skinny_ws_bytes;
   int und_rounding;                    /* mode="und" rounding of the q/k norm and RoPE (qwen2_navit.py:526-530) */
-  void* decode_ws;                     /* optional, for BAGEL_LAYER_NORM_IN_GEMM: bagel_decode_attention_workspace_bytes(),
-                                          zeroed once by the caller; every row is then one sample's single new token
-                                          and tiles[i] describes row i */
+  void* decode_ws;                     /* optional: bagel_decode_attention_workspace_bytes(), zeroed once by the caller.
+                                          Says that every row is one sample's single new token and tiles[i] describes
+                                          row i; the layer then runs bagel_decode_attention_bf16 where it applies */
   long decode_ws_bytes;
+  long decode_max_kv;                  /* upper bound of a row's kv_len in decode mode (0: unknown) */
 } bagel_mot_rows;
 
 #define BAGEL_LAYER_KV_ONLY 1  /* stop once the layer's keys/values are in K_ws / Vt_ws (last layer of a prefill) */
@@ -183,7 +184,8 @@ typedef struct bagel_mot_rows {        /* one packed forward: activations, table
  * are each one sample's single new token (Bagel.generate_text, bagel.py:1551-1587; qwen2_navit.py:549-599), with the
  * keys of a sample split over workgroups and merged by the last one to finish.
  * workspace: bagel_decode_attention_workspace_bytes(), its first 256 bytes zero before the first call (the kernel
- * leaves them zero); calls sharing a workspace must not overlap.  Same finite-padding precondition on Vt_ws as
+ * leaves them zero); calls sharing a workspace must not overlap.  max_kv_len: an upper bound of every row's kv_len
+ * (sizes the grid; 0 = unknown, S is used).  Same finite-padding precondition on Vt_ws as
  * bagel_varlen_attention_bf16.  bagel_decode_attention_supported() != 0: rows * Hkv <= 64, Hq / Hkv 7 or 2,
  * head_dim 128 or 64. */
 int bagel_decode_attention_supported(int rows, int Hq, int Hkv, int head_dim);
@@ -191,7 +193,8 @@ long bagel_decode_attention_workspace_bytes(int rows, int Hq, int Hkv, int head_
 int bagel_decode_attention_bf16(const void* qkv, long ld, int rows, int Hq, int Hkv, int head_dim, const void* q_norm,
                                 const void* k_norm, const void* cos_table, const void* sin_table, const void* row_cs,
                                 const void* row_slot, const void* tiles, void* K_ws, void* Vt_ws, long S, void* O,
-                                float eps, int und_rounding, void* workspace, long workspace_bytes, void* stream);
+                                float eps, int und_rounding, long max_kv_len, void* workspace, long workspace_bytes,
+                                void* stream);
 
 /* One layer, in place on r->X.  K_ws [Hkv][S][D] and Vt_ws [Hkv][D][S] are THIS layer's workspace slices.
  * next_norm_gen / next_norm_und (optional): weights of the RMSNorm that follows the layer (the next layer's

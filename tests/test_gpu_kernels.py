@@ -103,19 +103,29 @@ def test_skinny_gemm(M, N, K):
     _close(C3, torch.nn.functional.silu((X.float() @ W.float().t() + b.float()).to(BF16)), ulps=3.0, what="skinny silu")
 
 
-def test_skinny_gemm_row_count_invariance():
+@pytest.mark.parametrize("N,Kd,epi", [(3584, 3584, "bias"), (3584, 18944, "residual"), (4608, 1792, "swiglu"),
+                                      (152064, 512, "bias")])
+def test_skinny_gemm_row_count_invariance(N, Kd, epi):
     """bagel_skinny_gemm_bf16: a row's result does not depend on how many rows share the launch (the packed CFG branches
-    rely on it)."""
+    and the packed batch rely on it) - across the kernel's row-group variants and its wide form for the vocabulary."""
     k = _K()
-    N, Kd = 3584, 3584
-    X, W, b = _rand((6, Kd), 1.0, 17).to(DEV), _rand((N, Kd), 0.03, 18).to(DEV), _rand((N,), 0.5, 19).to(DEV)
-    ws = torch.empty(k.skinny_workspace_bytes(6, N), dtype=torch.uint8, device=DEV)
-    C6 = torch.empty((6, N), dtype=BF16, device=DEV)
-    k.skinny_gemm(X, W, C6, ws, bias=b)
-    for rows in (1, 2, 4):
-        C = torch.empty((rows, N), dtype=BF16, device=DEV)
-        k.skinny_gemm(X[:rows], W, C, ws, bias=b)
-        assert torch.equal(C, C6[:rows])
+    g = torch.Generator(device=DEV).manual_seed(17)
+    X = torch.randn((64, Kd), generator=g, device=DEV).to(BF16)
+    W = (torch.randn((N, Kd), generator=g, device=DEV) * 0.03).to(BF16)
+    b = torch.randn((N,), generator=g, device=DEV).to(BF16) if epi == "bias" else None
+    ncol = N // 2 if epi == "swiglu" else N
+    R = torch.randn((64, ncol), generator=g, device=DEV).to(BF16) if epi == "residual" else None
+    code = {"bias": k.SK_BIAS, "residual": k.SK_RESIDUAL, "swiglu": k.SK_SWIGLU}[epi]
+    ws = torch.empty(k.skinny_workspace_bytes(64, N), dtype=torch.uint8, device=DEV)
+    full = torch.empty((64, ncol), dtype=BF16, device=DEV)
+    k.skinny_gemm(X, W, full, ws, bias=b, residual=R, epilogue=code)
+    ref = X.float() @ W.float().t()
+    if epi == "bias":
+        _close(full, (ref + b.float()).to(BF16), what="row-count invariance reference")
+    for rows in (1, 2, 6, 9, 16, 17, 33, 48):
+        C = torch.empty((rows, ncol), dtype=BF16, device=DEV)
+        k.skinny_gemm(X[:rows], W, C, ws, bias=b, residual=None if R is None else R[:rows], epilogue=code)
+        assert torch.equal(C, full[:rows]), f"{rows} rows differ from the same rows of a 64-row launch"
 
 
 def test_skinny_swiglu():

@@ -4,7 +4,7 @@ tower + prefill), greedy text decoding.  Prints one JSON line per workload.
 
     python tools/bench_workloads.py edit [--batch 8]
     python tools/bench_workloads.py prefill
-    python tools/bench_workloads.py think
+    python tools/bench_workloads.py think [--decode-batch 4]
 """
 import argparse
 import json
@@ -95,18 +95,18 @@ def prefill(model, dims, dev):
             "context_tokens_per_sec": sum(kv) / dt}
 
 
-def think(model, dims, dev, max_length):
-    """BASELINE config 5, text half: greedy decode of max_length tokens over a 400-token context."""
+def think(model, dims, dev, max_length, batch=1):
+    """BASELINE config 5, text half: greedy decode of max_length tokens over a 400-token context (per sample)."""
     ctx = 400
-    past = synthetic_context(dims, 1, ctx, dev, 5)
-    gi = model.prepare_start_tokens([ctx], [ctx], IDS)
+    past = synthetic_context(dims, batch, ctx, dev, 5)
+    gi = model.prepare_start_tokens([ctx] * batch, [ctx] * batch, IDS)
     run = lambda: model.generate_text(past_key_values=past, max_length=max_length, do_sample=False, **gi)  # noqa: E731
     model.generate_text(past_key_values=past, max_length=8, do_sample=False, **gi)
     toks, dt = timed(run)
     w = model.engine.w
     bytes_per_token = sum(t.numel() * 2 for lw in w.layers for t in (lw.wqkv[1], lw.wo[1], lw.wgu[1], lw.wd[1])) + w.lm_head.numel() * 2
-    return {"workload": f"think: greedy decode, {max_length} tokens, batch 1, context {ctx}", "seconds": dt,
-            "tokens_per_sec": toks.shape[0] / dt, "ms_per_token": dt / toks.shape[0] * 1e3,
+    return {"workload": f"think: greedy decode, {max_length} tokens, batch {batch}, context {ctx}", "seconds": dt,
+            "tokens_per_sec": toks.shape[0] * batch / dt, "ms_per_token": dt / toks.shape[0] * 1e3,
             "weight_bytes_per_token": bytes_per_token, "achieved_GBps": bytes_per_token * toks.shape[0] / dt / 1e9}
 
 
@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--num-timesteps", type=int, default=50)
     ap.add_argument("--max-length", type=int, default=300)
+    ap.add_argument("--decode-batch", type=int, default=1, help="samples decoded together (think)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dims = BAGEL_7B
@@ -133,7 +134,7 @@ def main():
     elif args.workload == "prefill":
         out = prefill(model, dims, dev)
     else:
-        out = think(model, dims, dev, args.max_length)
+        out = think(model, dims, dev, args.max_length, args.decode_batch)
     out.update({"dims": "BAGEL-7B-MoT (28 layers) + SigLIP so400m (26 layers) + FLUX VAE", "data": "synthetic, random-init weights",
                 "n_gpus": 1, "dtype": "bf16"})
     print(json.dumps(out))

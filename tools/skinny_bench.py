@@ -13,8 +13,10 @@ SHAPES = [("qkv", 4608, 3584, K.SK_BIAS), ("o_proj", 3584, 3584, K.SK_RESIDUAL),
 
 def main():
     dev = "cuda:0"
-    for gemv in (0, 1):                     # 0: split-K MFMA form + reduce launch, 1: one-launch form (a wave owns whole rows)
-      print(f"--- form {gemv}")
+    for form in (0, 1, 2):    # 0: split-K MFMA + reduce launch, 1: one-launch v_dot2c form (a wave owns whole rows), 2: one-launch MFMA
+      gemv = form == 1
+      K.lib().bagel_set_stream_mfma(1 if form == 2 else 0)
+      print(f"--- form {form}")
       for M in [int(v) for v in sys.argv[1:]] or [6, 1]:
           total_t = total_b = 0.0
           for name, N, Kd, epi in SHAPES:
