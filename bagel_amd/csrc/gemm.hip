@@ -22,7 +22,6 @@
 //   EPI_F32_SCALED     C (fp32) = alpha * acc                 attention scores of the VAE mid block
 //   EPI_BIAS_GELU      C = bf16(gelu_tanh(bf16(acc + bias)))    SiglipMLP.fc1 / MLPconnector.fc1 + activation
 #include "gemm_tile.h"
-#include "gemm_pingpong.h"
 #include "gemm_pipelined.h"
 #include <algorithm>
 
@@ -48,32 +47,6 @@ static int launch_gemm(GemmParams p, int epilogue, hipStream_t stream) {
 #define LAUNCH(EPI)                                                                              \
   do {                                                                                           \
     auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, EPI, A_DENSE>;                                        \
-    static BagelLdsAllowed allowed;                                                              \
-    bagel_allow_lds(allowed, (const void*)kern, (int)lds);                                       \
-    hipLaunchKernelGGL(kern, grid, block, lds, stream, p);                                       \
-  } while (0)
-  switch (epilogue) {
-    case EPI_BIAS: LAUNCH(EPI_BIAS); break;
-    case EPI_RESIDUAL: LAUNCH(EPI_RESIDUAL); break;
-    case EPI_SWIGLU: LAUNCH(EPI_SWIGLU); break;
-    case EPI_BIAS_RESIDUAL: LAUNCH(EPI_BIAS_RESIDUAL); break;
-    case EPI_F32_SCALED: LAUNCH(EPI_F32_SCALED); break;
-    case EPI_BIAS_GELU: LAUNCH(EPI_BIAS_GELU); break;
-    default: bagel_set_error("bagel_gemm_bf16: unknown epilogue %d", epilogue); return 1;
-  }
-#undef LAUNCH
-  BAGEL_LAUNCH_CHECK();
-  return 0;
-}
-
-static int launch_pingpong(GemmParams p, int epilogue, hipStream_t stream) {
-  p.tiles_m = (p.M + 255) / 256;
-  p.tiles_n = (p.N + 255) / 256;
-  const dim3 grid(p.tiles_m * p.tiles_n), block(512);
-  const size_t lds = 2 * (256 + 256) * ROW_BYTES;
-#define LAUNCH(EPI)                                                                              \
-  do {                                                                                           \
-    auto kern = gemm256_pingpong_kernel<EPI>;                                                    \
     static BagelLdsAllowed allowed;                                                              \
     bagel_allow_lds(allowed, (const void*)kern, (int)lds);                                       \
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);                                       \
@@ -186,17 +159,16 @@ extern "C" int bagel_gemm_bf16(const void* A, long lda, const void* W, long ldw,
   p.diag = g_gemm_diag;
 #endif
   // 256-row software-pipelined tiles (8 waves, one workgroup per CU) or 128x128 tiles (4 waves, two
-  // workgroups per CU).  Measured on the 7B gate+up shape (random operands): 128x128 1.10, 256x256
-  // one-barrier loop 1.25, ping-pong 1.29, software-pipelined 1.38 PFLOP/s.
+  // workgroups per CU).  Measured on the 7B gate+up shape (random operands): 128x128 1.10, software-pipelined
+  // 1.38 PFLOP/s (a 256x256 one-barrier loop reached 1.25 and a ping-pong schedule 1.29; neither is kept).
   const int variant = g_gemm_variant >= 0 ? g_gemm_variant : choose_gemm_variant(M, N, epilogue);
   switch (variant) {
-    case 1: return launch_gemm<256, 256, 2, 4>(p, epilogue, (hipStream_t)stream);
-    case 2: return launch_pingpong(p, epilogue, (hipStream_t)stream);
     case 3: return launch_pipelined<256, 2>(p, epilogue, (hipStream_t)stream);
     case 4: return launch_pipelined<224, 4>(p, epilogue, (hipStream_t)stream);
     case 5: return launch_pipelined<288, 4>(p, epilogue, (hipStream_t)stream);
     case 6: return launch_pipelined<256, 4>(p, epilogue, (hipStream_t)stream);
-    default: return launch_gemm<128, 128, 2, 2>(p, epilogue, (hipStream_t)stream);
+    case 0: return launch_gemm<128, 128, 2, 2>(p, epilogue, (hipStream_t)stream);
+    default: bagel_set_error("bagel_gemm_bf16: unknown tile variant %d", variant); return 1;
   }
 }
 

@@ -45,7 +45,10 @@ int bagel_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, l
 /* Same contraction for M <= 64 rows, streaming every weight byte once (HBM-bound).
  * Replaces the understanding expert's nn.Linear calls on the two text tokens of each sample
  * (qwen2_navit.py:540,543,546,604,832) and TimestepEmbedder.mlp (modeling_utils.py:80-84,111).
- * N % 16 == 0, K % 128 == 0.  `workspace` holds fp32 split-K partials. */
+ * N % 16 == 0, K % 128 == 0.  One launch: the K slices of a block of 16 weight rows are the waves of one workgroup
+ * and meet in LDS.  A row's result does not depend on M (the K split is a function of N and K alone).
+ * `workspace` (bagel_skinny_gemm_workspace_bytes) is only touched by the split-K fallback, taken when ldc / ldr are
+ * not multiples of 4 elements or C / residual are not 8-byte aligned. */
 long bagel_skinny_gemm_workspace_bytes(int M, int N);
 int bagel_skinny_gemm_bf16(const void* X, long ldx, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
                            const void* bias, const void* residual, long ldr, int epilogue, void* workspace,
@@ -66,12 +69,12 @@ int bagel_skinny_gemm_residual_rmsnorm_bf16(const void* X, long ldx, const void*
  * norm + lm_head: qwen2_navit.py:798-801, 826-832, 1098-1105, 1204).  With at most 4 rows (2 for SwiGLU and for
  * N > 16384) and K % 512 == 0 the rows are normalised inside the weight-streaming kernel and nothing else is
  * launched; otherwise RMSNorm runs into the caller's Xn rows ([M][ldn], may be NULL when the fused form applies:
- * bagel_skinny_gemv_eligible) and the split-K form follows.  epilogue: BAGEL_SK_BIAS, BAGEL_SK_SWIGLU, BAGEL_SK_BIAS_SILU. */
+ * bagel_skinny_gemv_eligible) and bagel_skinny_gemm_bf16 follows.  epilogue: BAGEL_SK_BIAS, BAGEL_SK_SWIGLU, BAGEL_SK_BIAS_SILU. */
 int bagel_skinny_gemv_eligible(int M, int N, int K, int epilogue);
 
 /* bagel_skinny_gemm_bf16's contract in the one-launch form where bagel_skinny_gemv_eligible() accepts the shape (a wave
- * owns whole weight rows: no partial sums, other fp32 summation order), the split-K form otherwise.  For the decode
- * loop; bagel_skinny_gemm_bf16 itself always takes the split-K form, so that a row's result never depends on how many
+ * owns whole weight rows: other fp32 summation order), bagel_skinny_gemm_bf16 itself otherwise.  For the decode
+ * loop; bagel_skinny_gemm_bf16 never takes this form, so that a row's result never depends on how many
  * rows share the launch. */
 int bagel_skinny_gemv_bf16(const void* X, long ldx, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
                            const void* bias, const void* residual, long ldr, int epilogue, void* workspace,

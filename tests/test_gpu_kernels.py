@@ -85,9 +85,18 @@ def test_gemm_swiglu(M, I, K):
     _close(C, ref, ulps=3.0, what="gemm swiglu")
 
 
+@pytest.fixture(params=["one_launch", "split_k"])
+def skinny_form(request):
+    """Both forms of bagel_skinny_gemm_bf16: the one-launch MFMA kernel (default) and the split-K + reduce fallback."""
+    lib = _K().lib()
+    lib.bagel_set_stream_mfma(1 if request.param == "one_launch" else 0)
+    yield request.param
+    lib.bagel_set_stream_mfma(1)
+
+
 @pytest.mark.parametrize("M", [1, 2, 6, 16, 17, 48, 64])
 @pytest.mark.parametrize("N,K", [(512, 256), (4608, 3584), (3584, 18944)])
-def test_skinny_gemm(M, N, K):
+def test_skinny_gemm(M, N, K, skinny_form):
     k = _K()
     X, W, b = _rand((M, K), 1.0, 10), _rand((N, K), 0.03, 11), _rand((N,), 0.5, 12)
     ws = torch.empty(k.skinny_workspace_bytes(M, N), dtype=torch.uint8, device=DEV)
@@ -128,10 +137,11 @@ def test_skinny_gemm_row_count_invariance(N, Kd, epi):
         assert torch.equal(C, full[:rows]), f"{rows} rows differ from the same rows of a 64-row launch"
 
 
-def test_skinny_swiglu():
+@pytest.mark.parametrize("M", [6, 20, 64])
+def test_skinny_swiglu(M, skinny_form):
     k = _K()
     from bagel_amd.engine import _interleave_gate_up
-    M, I, Kd = 6, 2304, 1792
+    I, Kd = 2304, 1792
     X, G, U = _rand((M, Kd), 1.0, 14), _rand((I, Kd), 0.03, 15), _rand((I, Kd), 0.03, 16)
     ws = torch.empty(k.skinny_workspace_bytes(M, 2 * I), dtype=torch.uint8, device=DEV)
     C = torch.empty((M, I), dtype=BF16, device=DEV)
@@ -440,12 +450,12 @@ def test_error_reporting():
         k.gemm(A, A, torch.zeros((8, 8), dtype=BF16, device=DEV))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 3, 4, 5, 6])
 @pytest.mark.parametrize("M,N,K,epi", [(700, 512, 256, "bias"), (512, 768, 1024, "residual"), (300, 1024, 192, "swiglu"),
                                        (4096, 4608, 3584, "bias"), (256, 256, 64, "bias"), (260, 256, 128, "residual"),
                                        (1024, 3584, 512, "residual"), (520, 228, 64, "bias")])
 def test_gemm_tile_variants(variant, M, N, K, epi):
-    """Every tile variant (128x128, 256x256 one-barrier / ping-pong / pipelined, 256x224, 256x288) must give the
+    """Every tile variant (128x128, 256x256 pipelined in both wave layouts, 256x224, 256x288) must give the
     same answers, ragged M and N included."""
     k = _K()
     lib = k.lib()

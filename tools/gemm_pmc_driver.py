@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bagel_amd import _lib as K  # noqa: E402
 
-variants = [int(v) for v in sys.argv[1:]] or [1, 2]
+variants = [int(v) for v in sys.argv[1:]] or [0, 6]
 M, N, Kd = 12288, 37888, 3584
 A = torch.randn((M, Kd), device="cuda:0", dtype=torch.bfloat16)
 W = torch.randn((N, Kd), device="cuda:0", dtype=torch.bfloat16) * 0.02
