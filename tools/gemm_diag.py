@@ -51,6 +51,9 @@ def main():
     for name, M, N, Kd, epi in SHAPES:
         A = torch.randn((M, Kd), device=dev, dtype=torch.bfloat16)
         W = torch.randn((N, Kd), device=dev, dtype=torch.bfloat16) * 0.02
+        if os.environ.get("OPERANDS") == "zeros":    # how much of the time is the power the data's switching costs
+            A.zero_()
+            W.zero_()
         C = torch.empty((M, N // 2 if epi == K.EPI_SWIGLU else N), device=dev, dtype=torch.bfloat16)
         R = torch.randn_like(C) if epi == K.EPI_RESIDUAL else None
         b = torch.randn((N,), device=dev, dtype=torch.bfloat16) if epi == K.EPI_BIAS else None
