@@ -134,6 +134,9 @@ def main():
     elif args.workload == "prefill":
         out = prefill(model, dims, dev)
     else:
+        if os.environ.get("DECODE_MIN_CHUNK"):   # development: keys per workgroup of the one-launch decode attention
+            from bagel_amd import _lib as K
+            K.lib().bagel_set_decode_min_chunk(int(os.environ["DECODE_MIN_CHUNK"]))
         out = think(model, dims, dev, args.max_length, args.decode_batch)
     out.update({"dims": "BAGEL-7B-MoT (28 layers) + SigLIP so400m (26 layers) + FLUX VAE", "data": "synthetic, random-init weights",
                 "n_gpus": 1, "dtype": "bf16"})
