@@ -25,12 +25,21 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16* __restrict__ x
   bf16* orow = out + (long)row * ldo;
   float ss = 0.f;
   if constexpr (MAXC > 0) {
-    bf16x8 v[MAXC];
+    // the weights are requested with the row, not after its statistics: a few-row launch (a decode step) is two
+    // dependent memory round trips otherwise
+    bf16x8 v[MAXC], wv[MAXC];
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = lane * 8 + i * 512;
       if (c < H) {
         v[i] = *(const bf16x8*)(xr + c);
+        wv[i] = *(const bf16x8*)(w + c);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane * 8 + i * 512;
+      if (c < H) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) ss += (float)v[i][j] * (float)v[i][j];
       }
@@ -41,10 +50,9 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16* __restrict__ x
     for (int i = 0; i < MAXC; ++i) {
       const int c = lane * 8 + i * 512;
       if (c < H) {
-        const bf16x8 wv = *(const bf16x8*)(w + c);
         bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)wv[j] * round_bf16((float)v[i][j] * rs));
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)wv[i][j] * round_bf16((float)v[i][j] * rs));
         *(bf16x8*)(orow + c) = o;
       }
     }
