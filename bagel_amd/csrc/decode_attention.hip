@@ -7,7 +7,7 @@
 // attention kernel whose 128-row query tiles carry one live row); a decode step is latency, not throughput, so:
 //
 //   grid = (key chunks, kv heads, samples), 1024 threads.  A workgroup takes one sample, one kv head with the REP
-//   query heads that share it, and one chunk of that sample's keys (256 keys, more when the sample has over 8192).
+//   query heads that share it, and one chunk of that sample's keys (256 keys, more when the sample has over 16384).
 //   Its four groups of four waves take one 64-key tile each per round, each with its own online softmax, and are
 //   merged through LDS.  The first two rounds' keys and values are requested before anything else, so the norm + RoPE of the
 //   queries (a few hundred flops, recomputed by every workgroup) runs under that latency.  The workgroup whose
@@ -15,7 +15,7 @@
 //   into its own registers from LDS, so nothing is read back from memory inside the launch.
 //   A sample of more than one chunk is split over workgroups: every workgroup leaves an unnormalised partial (max,
 //   sum, REP x D accumulators, fp32) and the last one of a (sample, kv head) to finish - found with one atomic
-//   ticket, released and acquired by one thread per workgroup - merges them.  No workgroup ever waits for another.
+//   ticket - merges them.  No workgroup ever waits for another.
 //   (Measured inside the 7B decode step at 400-700 keys: 12.5 us against 22.9 us for the three launches; one
 //   workgroup per kv head walking all tiles took 15-21 us, a fence in every wave 27 us.)
 //
@@ -33,7 +33,7 @@ struct DecTile {   // same 32-byte record as the tiled kernel's table
   int q_row0, n_rows, kv_start, kv_len, causal_base, pad[3];
 };
 
-constexpr int MAX_SPLITS = 32;   // key chunks per sample (grid.x)
+constexpr int MAX_SPLITS = 64;   // key chunks per sample (grid.x)
 constexpr int TK = 64;           // keys per tile
 
 struct DecParams {
@@ -264,39 +264,53 @@ __global__ __launch_bounds__(1024) void decode_attention_kernel(DecParams p) {
     if (mine_out) orow[tid] = (bf16)(o_sum / l_sum);
     return;
   }
+  // Partials travel between workgroups (often between XCDs, whose L2s are not coherent with each other) through
+  // device-scope accesses: write-through stores, then the ticket, then device-scope loads in the last workgroup.
+  // A release / acquire fence pair instead costs an L2 write-back per workgroup, and those queue up per XCD: with 18
+  // chunks per kv head (9 k keys) the launch took 30 us longer than this form.
   float* part = p.part + (((long)m * p.Hkv + g) * MAX_SPLITS) * REP * PW;
   if (mine_out) {
     float* mine = part + ((long)c * REP + oh) * PW;
-    mine[od] = o_sum;
+    __hip_atomic_store(mine + od, o_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (od == 0) {
-      mine[D] = mx;
-      mine[D + 1] = l_sum;
+      __hip_atomic_store(mine + D, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mine + D + 1, l_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  // ticket: after the barrier one thread releases the workgroup's partial stores device-wide and counts it in; in the
-  // last workgroup the same thread's acquire precedes the barrier that lets the others read
+  // every wave's stores have completed (the barrier's release waits for them) before one thread counts the workgroup in
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   unsigned* ticket = p.tickets + (long)m * p.Hkv + g;
-  if (tid == 0) {
-    __threadfence();
-    ticket_s = atomicAdd(ticket, 1u);
-    __threadfence();
-  }
+  if (tid == 0) ticket_s = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (ticket_s != (unsigned)(nsplit - 1)) return;
   if (mine_out) {
-    float gm = -INFINITY;
-    for (int s2 = 0; s2 < nsplit; ++s2) gm = fmaxf(gm, part[((long)s2 * REP + oh) * PW + D]);
-    float l = 0.f, o = 0.f;
-    for (int s2 = 0; s2 < nsplit; ++s2) {
-      const float* ps = part + ((long)s2 * REP + oh) * PW;
-      const float wgt = exp2f(ps[D] - gm);
-      l += ps[D + 1] * wgt;
-      o += ps[od] * wgt;
+    // one pass over the chunks, eight at a time so that their loads are in flight together
+    float gm = -INFINITY, l = 0.f, o = 0.f;
+    for (int s0 = 0; s0 < nsplit; s0 += 8) {
+      float pm[8], pl[8], po[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float* ps = part + ((long)min(s0 + i, nsplit - 1) * REP + oh) * PW;
+        pm[i] = __hip_atomic_load(ps + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pl[i] = __hip_atomic_load(ps + D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        po[i] = __hip_atomic_load(ps + od, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (s0 + i < nsplit) {
+          const float nm = fmaxf(gm, pm[i]);
+          const float a = exp2f(gm - nm), w = exp2f(pm[i] - nm);   // gm = -inf only before the first chunk: a = 0
+          l = l * a + pl[i] * w;
+          o = o * a + po[i] * w;
+          gm = nm;
+        }
+      }
     }
     orow[tid] = (bf16)(o / l);
   }
-  if (tid == 0) atomicExch(ticket, 0u);   // ready for the next launch
+  if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
 }  // namespace

@@ -95,9 +95,8 @@ def prefill(model, dims, dev):
             "context_tokens_per_sec": sum(kv) / dt}
 
 
-def think(model, dims, dev, max_length, batch=1):
-    """BASELINE config 5, text half: greedy decode of max_length tokens over a 400-token context (per sample)."""
-    ctx = 400
+def think(model, dims, dev, max_length, batch=1, ctx=400):
+    """BASELINE config 5, text half: greedy decode of max_length tokens over a ctx-token context (per sample)."""
     past = synthetic_context(dims, batch, ctx, dev, 5)
     gi = model.prepare_start_tokens([ctx] * batch, [ctx] * batch, IDS)
     run = lambda: model.generate_text(past_key_values=past, max_length=max_length, do_sample=False, **gi)  # noqa: E731
@@ -117,6 +116,7 @@ def main():
     ap.add_argument("--num-timesteps", type=int, default=50)
     ap.add_argument("--max-length", type=int, default=300)
     ap.add_argument("--decode-batch", type=int, default=1, help="samples decoded together (think)")
+    ap.add_argument("--context", type=int, default=400, help="context tokens per sample (think)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dims = BAGEL_7B
@@ -137,7 +137,7 @@ def main():
         if os.environ.get("DECODE_MIN_CHUNK"):   # development: keys per workgroup of the one-launch decode attention
             from bagel_amd import _lib as K
             K.lib().bagel_set_decode_min_chunk(int(os.environ["DECODE_MIN_CHUNK"]))
-        out = think(model, dims, dev, args.max_length, args.decode_batch)
+        out = think(model, dims, dev, args.max_length, args.decode_batch, args.context)
     out.update({"dims": "BAGEL-7B-MoT (28 layers) + SigLIP so400m (26 layers) + FLUX VAE", "data": "synthetic, random-init weights",
                 "n_gpus": 1, "dtype": "bf16"})
     print(json.dumps(out))
