@@ -475,6 +475,217 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_kernel(const bf16* __restric
   }
 }
 
+// The same kernel with the weights brought in by LDS-DMA: the register form reads a weight row in 64-byte pieces (the
+// MFMA operand layout ties four lanes to a row), two instructions per 128-byte line, which costs twice the requests
+// per byte and rules out the non-temporal policy.  Here a wave's DMA instruction moves 1 KiB = four rows x 256
+// contiguous bytes (whole lines, non-temporal) into the wave's own ring of S slots in LDS - no other wave touches it,
+// so a counted s_waitcnt is the only synchronisation - and the MFMA fragments are read from there (16-byte chunk
+// index XOR row, applied to the DMA source address and to the read, spreads the 16 rows over all banks).
+// K slices, step order and the reduction are those of the register form: the two give the same bits.
+template <int G, int RB, int S>
+__global__ __launch_bounds__(512) void stream_dma_kernel(const bf16* __restrict__ X, long ldx, const bf16* __restrict__ W,
+                                                         long ldw, bf16* __restrict__ C, long ldc, int M, int N, int K,
+                                                         const bf16* __restrict__ bias, const bf16* __restrict__ R,
+                                                         long ldr, int epilogue, int ns) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor builtins exist only in the device pass
+  extern __shared__ __attribute__((aligned(16))) char dma_smem[];
+  constexpr int SLOT = RB * 4096;          // one 128-deep step of the workgroup's RB row blocks
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+  const int r = lane & 15, h = lane >> 4;
+  const int row0 = blockIdx.x * (16 * RB);
+  const int nsteps = K / 128;
+  char* ring = dma_smem + wave * (S * SLOT);
+  f32x4* red_s = (f32x4*)(dma_smem + nw * (S * SLOT));   // [ns][RB][G][64]
+  // DMA: piece i of a block is rows 4 i .. 4 i + 3; lane l lands at byte 16 l of the piece = row 4 i + (l >> 4),
+  // position l & 15, and fetches the chunk that belongs there
+  // (buffer addressing: the compiler's wait-count pass treats the global form of the DMA load as a flat access that may
+  // touch LDS and then drains every counter at the first register use of an ordinary load)
+  const bf16* w_base = W + (long)row0 * ldw;
+  int dvoff[RB][4];
+#pragma unroll
+  for (int b = 0; b < RB; ++b)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = 4 * i + (lane >> 4);
+      dvoff[b][i] = (int)(((long)(b * 16 + rr) * ldw + (((lane & 15) ^ rr) * 8)) * 2);
+    }
+  int rd_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rd_off[j] = r * 256 + (((4 * j + h) ^ r) * 16);
+  const bf16* xp[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) xp[g] = X + (long)min(g * 16 + r, M - 1) * ldx + h * 8;
+
+  auto issue = [&](int slot, int step) {
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, LDS_PTR(ring + slot * SLOT + b * 4096 + i * 1024), 16, dvoff[b][i],
+                                                 step * 256, 0, 2 /* non-temporal */);
+  };
+  // X fragments travel with the slots, S - 1 steps ahead, in a register ring: requested right behind the slot's DMA,
+  // they complete in the same order, and one count covers both
+  bf16x8 xf[S][G][4];
+  auto xload = [&](const int B, int step) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf[B][g][j] = *(const bf16x8*)(xp[g] + step * 128 + j * 32);
+  };
+  // the wave's steps, slice after slice: slice q is steps q, q + ns, ...; the wave takes slices wave, wave + nw, ...
+  auto advance = [&](int& q, int& st) {
+    st += ns;
+    if (st >= nsteps) {
+      q += nw;
+      st = q;
+    }
+  };
+  f32x4 acc[RB][G];
+#pragma unroll
+  for (int b = 0; b < RB; ++b)
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[b][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int pq = wave, ps = wave;   // producer: next step to request
+  int cq = wave, cs = wave;   // consumer: step being multiplied
+#pragma unroll
+  for (int k = 0; k < S - 1; ++k)
+    if (pq < ns) {
+      issue(k, ps);
+      xload(k, ps);
+      advance(pq, ps);
+    }
+  // one step out of slot B (B and FULL are literals at every call and the lambda is always inlined, so both fold).
+  // FULL: the steady state, where the step requests the slot S - 1 ahead and the wait count is exact.
+  auto step = [&](const int B, const bool FULL) __attribute__((always_inline)) {
+    constexpr int AHEAD = (S - 1) * (4 * RB + 4 * G);
+    static_assert(AHEAD < 64, "vmcnt is a 6-bit count");
+    if (FULL) {
+      issue((B + S - 1) % S, ps);
+      xload((B + S - 1) % S, ps);
+      advance(pq, ps);
+      // everything older than the S - 1 steps in flight has landed: this step's slot and X fragments
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(AHEAD) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const char* slot = ring + B * SLOT;
+    bf16x8 wf[RB][4];
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[b][j] = *(const bf16x8*)(slot + b * 4096 + rd_off[j]);
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[b][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b][j], xf[B][g][j], acc[b][g], 0, 0, 0);
+    int nq = cq, nst = cs;
+    advance(nq, nst);
+    if (nq != cq) {   // the slice is complete
+#pragma unroll
+      for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          red_s[((cq * RB + b) * G + g) * 64 + lane] = acc[b][g];
+          acc[b][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    cq = nq;
+    cs = nst;
+  };
+  // steps of this wave: slice q has nsteps / ns steps, one more when q < nsteps % ns
+  int total = 0;
+  {
+    const int base = nsteps / ns, rem = nsteps - base * ns;
+    for (int q = wave; q < ns; q += nw) total += base + (q < rem ? 1 : 0);
+  }
+  const int full = max(total - (S - 1), 0);   // steps that still have a slot to request
+  int i = 0;
+  for (; i + S <= full; i += S) {
+    step(0, true);
+    step(1, true);
+    if (S > 2) step(2 % S, true);
+    if (S > 3) step(3 % S, true);
+  }
+  // fewer than S steps that request, then the at most S - 1 steps already requested
+  int slot = 0;
+  for (; i < total; ++i) {
+    const bool f = i < full;
+    if (slot == 0) {
+      if (f) step(0, true);
+      else step(0, false);
+    } else if (slot == 1) {
+      if (f) step(1, true);
+      else step(1, false);
+    } else if (S > 2 && slot == 2) {
+      if (f) step(2 % S, true);
+      else step(2 % S, false);
+    } else if (S > 3) {
+      if (f) step(3 % S, true);
+      else step(3 % S, false);
+    }
+    slot = slot + 1 == S ? 0 : slot + 1;
+  }
+  __syncthreads();
+  if (wave >= G) return;
+  const int m = wave * 16 + r;
+  f32x4 v[RB];
+#pragma unroll
+  for (int b = 0; b < RB; ++b) {
+    v[b] = red_s[(b * G + wave) * 64 + lane];
+    for (int q = 1; q < ns; ++q) v[b] += red_s[((q * RB + b) * G + wave) * 64 + lane];
+  }
+  if (m >= M) return;
+  bf16x4 out;
+  if (epilogue == SK_SWIGLU) {
+    if constexpr (RB >= 2) {
+#pragma unroll
+      for (int pr = 0; pr < RB / 2; ++pr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          out[i] = (bf16)(round_bf16(silu_f32(round_bf16(v[2 * pr][i]))) * round_bf16(v[2 * pr + 1][i]));
+        *(bf16x4*)(C + (long)m * ldc + (blockIdx.x * (RB / 2) + pr) * 16 + h * 4) = out;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int b = 0; b < RB; ++b) {
+    const int n = row0 + b * 16 + h * 4;
+    bf16x4 rv = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    if (epilogue == SK_RESIDUAL) rv = *(const bf16x4*)(R + (long)m * ldr + n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a = v[b][i];
+      if (bias) a += (float)bias[n + i];
+      if (epilogue == SK_RESIDUAL) a = round_bf16(a) + (float)rv[i];
+      if (epilogue == SK_BIAS_SILU) a = silu_f32(round_bf16(a));
+      out[i] = (bf16)a;
+    }
+    *(bf16x4*)(C + (long)m * ldc + n) = out;
+  }
+#endif
+}
+
+static int g_stream_dma = 1;   // development knob: 0 keeps the register form at up to 16 rows too (bagel_set_stream_dma)
+extern "C" void bagel_set_stream_dma(int on) { g_stream_dma = on; }
+
+template <int G, int RB, int S>
+static void stream_dma_launch_one(const bf16* X, long ldx, const bf16* W, long ldw, bf16* C, long ldc, int M, int N, int K,
+                                  const bf16* bias, const bf16* R, long ldr, int epilogue, int ns, hipStream_t st) {
+  const int blocks = N / (16 * RB);
+  const int nw = std::max(G, std::min(ns, 8));
+  const size_t lds = (size_t)nw * S * RB * 4096 + (size_t)ns * RB * G * 1024;
+  static BagelLdsAllowed allowed;
+  bagel_allow_lds(allowed, (const void*)stream_dma_kernel<G, RB, S>, 160 * 1024);
+  hipLaunchKernelGGL((stream_dma_kernel<G, RB, S>), dim3(blocks), dim3(64 * nw), lds, st, X, ldx, W, ldw, C, ldc, M, N, K, bias,
+                     R, ldr, epilogue, ns);
+}
+
 // Waves per workgroup: enough waves on the chip (about 24 per CU when the shape allows) and K steps that divide evenly.
 static int stream_waves_per_block(int blocks, int ksteps, int max_nw) {
   const long want = 24L * bagel_cu_count();
@@ -520,6 +731,11 @@ static void stream_launch(const bf16* X, long ldx, const bf16* W, long ldw, bf16
   const int rb = sw ? 2 : 1;
   const int ns = stream_waves_per_block(N / (16 * rb), K / 128, 16 / rb);
   const bool wide = M > 8 && !sw && N % 64 == 0 && N / 64 >= 8 * bagel_cu_count() && ns * 4 * G <= 64;
+  if (g_stream_dma && G == 1 && !wide) {
+    if (sw) stream_dma_launch_one<1, 2, 2>(X, ldx, W, ldw, C, ldc, M, N, K, bias, R, ldr, epilogue, ns, st);
+    else stream_dma_launch_one<1, 1, 3>(X, ldx, W, ldw, C, ldc, M, N, K, bias, R, ldr, epilogue, ns, st);
+    return;
+  }
 #define STREAM(G_, RB_, MAXT_) stream_launch_one<G_, RB_, MAXT_>(X, ldx, W, ldw, C, ldc, M, N, K, bias, R, ldr, epilogue, ns, st)
   switch (G) {
     case 1: wide ? STREAM(1, 4, 512) : sw ? STREAM(1, 2, 1024) : STREAM(1, 1, 1024); break;
@@ -596,14 +812,17 @@ static int skinny_launch(const void* X, long ldx, const void* W, long ldw, void*
   if (epilogue == SK_RESIDUAL) BAGEL_CHECK(residual, "bagel_skinny_gemm_bf16: residual epilogue needs R");
   if (epilogue == SK_SWIGLU) BAGEL_CHECK(N % 32 == 0, "bagel_skinny_gemm_bf16: swiglu needs N %% 32 == 0");
   if (norm_weight) BAGEL_CHECK(Xn && epilogue == SK_RESIDUAL && N <= RN_THREADS * RN_MAXC, "bagel_skinny_gemm_residual_rmsnorm_bf16: bad arguments");
-  if (allow_gemv && g_skinny_gemv && !norm_weight && gemv_eligible(M, N, K, epilogue)) {
+  const bool stream_ok = g_stream_mfma && !norm_weight && ldc % 4 == 0 && (epilogue != SK_RESIDUAL || ldr % 4 == 0) &&
+                         ((uintptr_t)C | (uintptr_t)residual) % 8 == 0;
+  // three and four rows: the MFMA form with the weights brought in by DMA streams faster than four dot products per weight
+  const bool gemv_pays = M <= 2 || !(stream_ok && g_stream_dma);
+  if (allow_gemv && g_skinny_gemv && !norm_weight && gemv_pays && gemv_eligible(M, N, K, epilogue)) {
     gemv_launch((const bf16*)X, ldx, (const bf16*)W, ldw, (bf16*)C, ldc, M, N, K, (const bf16*)bias, (const bf16*)residual, ldr,
                 epilogue, nullptr, 0.f, (hipStream_t)stream);
     BAGEL_LAUNCH_CHECK();
     return 0;
   }
-  if (g_stream_mfma && !norm_weight && ldc % 4 == 0 && (epilogue != SK_RESIDUAL || ldr % 4 == 0) &&
-      ((uintptr_t)C | (uintptr_t)residual) % 8 == 0) {
+  if (stream_ok) {
     stream_launch((const bf16*)X, ldx, (const bf16*)W, ldw, (bf16*)C, ldc, M, N, K, (const bf16*)bias, (const bf16*)residual, ldr,
                   epilogue, (hipStream_t)stream);
     BAGEL_LAUNCH_CHECK();

@@ -85,13 +85,16 @@ def test_gemm_swiglu(M, I, K):
     _close(C, ref, ulps=3.0, what="gemm swiglu")
 
 
-@pytest.fixture(params=["one_launch", "split_k"])
+@pytest.fixture(params=["one_launch", "one_launch_registers", "split_k"])
 def skinny_form(request):
-    """Both forms of bagel_skinny_gemm_bf16: the one-launch MFMA kernel (default) and the split-K + reduce fallback."""
+    """The forms of bagel_skinny_gemm_bf16: the one-launch MFMA kernel (default; up to 16 rows it brings the weights in
+    by LDS-DMA), the same with the weights loaded to registers at every row count, and the split-K + reduce fallback."""
     lib = _K().lib()
-    lib.bagel_set_stream_mfma(1 if request.param == "one_launch" else 0)
+    lib.bagel_set_stream_mfma(0 if request.param == "split_k" else 1)
+    lib.bagel_set_stream_dma(0 if request.param == "one_launch_registers" else 1)
     yield request.param
     lib.bagel_set_stream_mfma(1)
+    lib.bagel_set_stream_dma(1)
 
 
 @pytest.mark.parametrize("M", [1, 2, 6, 16, 17, 48, 64])
@@ -135,6 +138,15 @@ def test_skinny_gemm_row_count_invariance(N, Kd, epi):
         C = torch.empty((rows, ncol), dtype=BF16, device=DEV)
         k.skinny_gemm(X[:rows], W, C, ws, bias=b, residual=None if R is None else R[:rows], epilogue=code)
         assert torch.equal(C, full[:rows]), f"{rows} rows differ from the same rows of a 64-row launch"
+    # up to 16 rows the weights come in by LDS-DMA, above that through registers: the register form at few rows, too
+    k.lib().bagel_set_stream_dma(0)
+    try:
+        for rows in (3, 16):
+            C = torch.empty((rows, ncol), dtype=BF16, device=DEV)
+            k.skinny_gemm(X[:rows], W, C, ws, bias=b, residual=None if R is None else R[:rows], epilogue=code)
+            assert torch.equal(C, full[:rows]), f"{rows} rows (register form) differ from a 64-row launch"
+    finally:
+        k.lib().bagel_set_stream_dma(1)
 
 
 @pytest.mark.parametrize("M", [6, 20, 64])

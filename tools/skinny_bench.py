@@ -13,9 +13,13 @@ SHAPES = [("qkv", 4608, 3584, K.SK_BIAS), ("o_proj", 3584, 3584, K.SK_RESIDUAL),
 
 def main():
     dev = "cuda:0"
-    for form in (0, 1, 2):    # 0: split-K MFMA + reduce launch, 1: one-launch v_dot2c form (a wave owns whole rows), 2: one-launch MFMA
+    forms = [int(v) for v in os.environ.get("FORMS", "0,1,2").split(",")]
+    # 0: split-K MFMA + reduce launch, 1: one-launch v_dot2c form (a wave owns whole rows), 2: one-launch MFMA,
+    # 3: one-launch MFMA with the weights brought in by LDS-DMA
+    for form in forms:
       gemv = form == 1
-      K.lib().bagel_set_stream_mfma(1 if form == 2 else 0)
+      K.lib().bagel_set_stream_mfma(1 if form >= 2 else 0)
+      K.lib().bagel_set_stream_dma(1 if form == 3 else 0)
       print(f"--- form {form}")
       for M in [int(v) for v in sys.argv[1:]] or [6, 1]:
           total_t = total_b = 0.0
@@ -31,6 +35,13 @@ def main():
               ws = torch.empty((16 * M * N,), device=dev, dtype=torch.float32)
               for W in Ws:
                   K.skinny_gemm(X, W, C, ws, bias=b, residual=R, epilogue=epi, gemv=bool(gemv))
+              if form == 3:
+                  K.lib().bagel_set_stream_dma(0)
+                  C2 = torch.empty_like(C)
+                  K.skinny_gemm(X, Ws[-1], C2, ws, bias=b, residual=R, epilogue=epi)
+                  K.lib().bagel_set_stream_dma(1)
+                  torch.cuda.synchronize()
+                  assert torch.equal(C, C2), (name, M, float((C.float() - C2.float()).abs().max()))
               times = []
               for it in range(12):
                   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
