@@ -146,13 +146,25 @@ SK_BIAS, SK_RESIDUAL, SK_SWIGLU, SK_BIAS_SILU = 0, 1, 2, 3
 RENORM = {"global": 0, "channel": 1, "text_channel": 2}
 
 
-def gemm(A, W, C, bias=None, residual=None, epilogue=EPI_BIAS, M=None, alpha=1.0):
-    """C[M,N] = epilogue(A[M,K] @ W[N,K]^T) (bf16 2-D tensors, rows may be strided)."""
+def gemm_workspace_bytes(M, N, K, epilogue=EPI_BIAS):
+    lib().bagel_gemm_workspace_bytes.restype = ctypes.c_long
+    return lib().bagel_gemm_workspace_bytes(I(M), I(N), I(K), I(epilogue))
+
+
+def gemm(A, W, C, bias=None, residual=None, epilogue=EPI_BIAS, M=None, alpha=1.0, workspace=None):
+    """C[M,N] = epilogue(A[M,K] @ W[N,K]^T) (bf16 2-D tensors, rows may be strided).  workspace: a tensor the split-K
+    form may use at 65 ... 512 rows (bagel_gemm_ws_bf16)."""
     M = A.shape[0] if M is None else M
     N, K = W.shape
     assert A.dtype == W.dtype == torch.bfloat16 and A.shape[1] == K
     assert C.dtype == (torch.float32 if epilogue == EPI_F32_SCALED else torch.bfloat16)
     assert A.stride(1) == 1 and W.stride(1) == 1 and C.stride(1) == 1
+    if workspace is not None:
+        _check(lib().bagel_gemm_ws_bf16(_p(A), L(A.stride(0)), _p(W), L(W.stride(0)), _p(C), L(C.stride(0)), I(M), I(N), I(K),
+                                        _p(bias), _p(residual), L(residual.stride(0) if residual is not None else 0),
+                                        I(epilogue), F(alpha), _p(workspace), L(workspace.numel() * workspace.element_size()),
+                                        _stream()), "bagel_gemm_ws_bf16")
+        return C
     _check(lib().bagel_gemm_bf16(_p(A), L(A.stride(0)), _p(W), L(W.stride(0)), _p(C), L(C.stride(0)), I(M), I(N), I(K),
                                  _p(bias), _p(residual), L(residual.stride(0) if residual is not None else 0),
                                  I(epilogue), F(alpha), _stream()), "bagel_gemm_bf16")

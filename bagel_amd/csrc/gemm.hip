@@ -65,6 +65,73 @@ static int launch_gemm(GemmParams p, int epilogue, hipStream_t stream) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-K for row counts between the weight-streaming kernels and a chip-filling tile count (65 ... 512 rows of a
+// projection with few column tiles: a text prompt's prefill).  One 128 x 128 tile per 128 output features is 28-36
+// workgroups walking the whole reduction one after the other; K slices put SPLIT times as many on the chip, their fp32
+// partial tiles go through a workspace, and a second launch adds them in slice order and applies the epilogue.
+// The split depends on (N, K) only, so a row's result does not depend on how many rows share the launch.
+// ---------------------------------------------------------------------------------------------
+constexpr int SPLITK_MAX_ROWS = 512;
+
+static int gemm_ksplit(int M, int N, int K, int epilogue) {
+  if (M <= 64 || M > SPLITK_MAX_ROWS) return 1;
+  if (epilogue != EPI_BIAS && epilogue != EPI_RESIDUAL && epilogue != EPI_BIAS_RESIDUAL && epilogue != EPI_BIAS_GELU) return 1;
+  const int tiles_n = (N + 127) / 128, nk = K / BK;
+  int ks = std::min(256 / tiles_n, nk / 4);
+  if (ks < 2) return 1;
+  const int per = (nk + ks - 1) / ks;
+  return (nk + per - 1) / per;   // every slice non-empty
+}
+
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int ksplit, long slab, int M, int N,
+                                                                 const bf16* __restrict__ bias, const bf16* __restrict__ R, long ldr,
+                                                                 bf16* __restrict__ C, long ldc, int epilogue) {
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;   // one thread: four features of one row
+  const int nq = N / 4;
+  if (q >= (long)M * nq) return;
+  const int m = (int)(q / nq), n = (int)(q - (long)m * nq) * 4;
+  const float* src = part + (long)m * N + n;
+  f32x4 a = *(const f32x4*)src;
+  for (int s = 1; s < ksplit; ++s) a += *(const f32x4*)(src + s * slab);
+  bf16x4 b4 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f}, r4 = b4, o;
+  if (bias != nullptr && epilogue != EPI_RESIDUAL) b4 = *(const bf16x4*)(bias + n);
+  if (epilogue == EPI_RESIDUAL || epilogue == EPI_BIAS_RESIDUAL) r4 = *(const bf16x4*)(R + (long)m * ldr + n);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {   // the arithmetic of gemm_epilogue()
+    if (epilogue == EPI_RESIDUAL) o[i] = (bf16)(round_bf16(a[i]) + (float)r4[i]);
+    else if (epilogue == EPI_BIAS_RESIDUAL) o[i] = (bf16)(round_bf16(a[i] + (float)b4[i]) + (float)r4[i]);
+    else if (epilogue == EPI_BIAS_GELU) o[i] = (bf16)gelu_tanh_f32(round_bf16(a[i] + (float)b4[i]));
+    else o[i] = (bf16)(a[i] + (float)b4[i]);
+  }
+  *(bf16x4*)(C + (long)m * ldc + n) = o;
+}
+
+static int launch_gemm_splitk(GemmParams p, int epilogue, int ksplit, float* workspace, hipStream_t stream) {
+  p.tiles_m = (p.M + 127) / 128;
+  p.tiles_n = (p.N + 127) / 128;
+  GemmParams q = p;
+  q.C = (bf16*)workspace;
+  q.ldc = p.N;
+  q.alpha = 1.0f;
+  q.ksplit = ksplit;
+  q.slab = (long)p.M * p.N;
+  q.bias = nullptr;
+  q.R = nullptr;
+  const dim3 grid(p.tiles_m * p.tiles_n, ksplit), block(256);
+  const size_t lds = 2 * (128 + 128) * ROW_BYTES;
+  auto kern = gemm_bf16_nt_kernel<128, 128, 2, 2, EPI_F32_SCALED, A_DENSE>;
+  static BagelLdsAllowed allowed;
+  bagel_allow_lds(allowed, (const void*)kern, (int)lds);
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, q);
+  BAGEL_LAUNCH_CHECK();
+  const long quads = (long)p.M * (p.N / 4);
+  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, workspace, ksplit, q.slab,
+                     p.M, p.N, p.bias, p.R, p.ldr, p.C, p.ldc, epilogue);
+  BAGEL_LAUNCH_CHECK();
+  return 0;
+}
+
 static int g_gemm_lead = -1;  // development knob: -1 automatic, 0 / 1 force the DMA split (bagel_set_gemm_lead)
 template <int BN, int WR>
 static int launch_pipelined(GemmParams p, int epilogue, hipStream_t stream) {
@@ -129,9 +196,9 @@ static int choose_gemm_variant(int M, int N, int epilogue) {
   return variant;
 }
 
-extern "C" int bagel_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N,
-                               int K, const void* bias, const void* residual, long ldr, int epilogue,
-                               float alpha, void* stream) {
+static int gemm_entry(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N,
+                      int K, const void* bias, const void* residual, long ldr, int epilogue,
+                      float alpha, void* workspace, long workspace_bytes, void* stream) {
   BAGEL_CHECK(A && W && C, "bagel_gemm_bf16: null operand");
   BAGEL_CHECK(M > 0 && N > 0 && K > 0, "bagel_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
   BAGEL_CHECK(K % BK == 0, "bagel_gemm_bf16: K=%d must be a multiple of %d", K, BK);
@@ -155,9 +222,17 @@ extern "C" int bagel_gemm_bf16(const void* A, long lda, const void* W, long ldw,
   p.R = (const bf16*)residual; p.ldr = ldr;
   p.M = M; p.N = N; p.K = K; p.alpha = alpha;
   p.diag = nullptr;
+  p.ksplit = 1;
+  p.slab = 0;
 #ifdef BAGEL_DIAG_CLOCK
   p.diag = g_gemm_diag;
 #endif
+  if (workspace != nullptr && g_gemm_variant < 0) {
+    const int ksplit = gemm_ksplit(M, N, K, epilogue);
+    if (ksplit > 1 && (uintptr_t)workspace % 16 == 0 && (long)ksplit * M * N * (long)sizeof(float) <= workspace_bytes &&
+        N % 4 == 0 && ldc % 4 == 0 && (uintptr_t)C % 8 == 0 && (bias == nullptr || (uintptr_t)bias % 8 == 0))
+      return launch_gemm_splitk(p, epilogue, ksplit, (float*)workspace, (hipStream_t)stream);
+  }
   // 256-row software-pipelined tiles (8 waves, one workgroup per CU) or 128x128 tiles (4 waves, two
   // workgroups per CU).  Measured on the 7B gate+up shape (random operands): 128x128 1.10, software-pipelined
   // 1.38 PFLOP/s (a 256x256 one-barrier loop reached 1.25 and a ping-pong schedule 1.29; neither is kept).
@@ -170,6 +245,26 @@ extern "C" int bagel_gemm_bf16(const void* A, long lda, const void* W, long ldw,
     case 0: return launch_gemm<128, 128, 2, 2>(p, epilogue, (hipStream_t)stream);
     default: bagel_set_error("bagel_gemm_bf16: unknown tile variant %d", variant); return 1;
   }
+}
+
+extern "C" int bagel_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N,
+                               int K, const void* bias, const void* residual, long ldr, int epilogue,
+                               float alpha, void* stream) {
+  return gemm_entry(A, lda, W, ldw, C, ldc, M, N, K, bias, residual, ldr, epilogue, alpha, nullptr, 0, stream);
+}
+
+// The same product with a workspace: 65 ... 512 rows of a projection with few column tiles take the split-K form when
+// the workspace holds bagel_gemm_workspace_bytes(M, N, K, epilogue); anything else runs as bagel_gemm_bf16 does.
+extern "C" int bagel_gemm_ws_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N,
+                                  int K, const void* bias, const void* residual, long ldr, int epilogue,
+                                  float alpha, void* workspace, long workspace_bytes, void* stream) {
+  return gemm_entry(A, lda, W, ldw, C, ldc, M, N, K, bias, residual, ldr, epilogue, alpha, workspace, workspace_bytes, stream);
+}
+
+extern "C" long bagel_gemm_workspace_bytes(int M, int N, int K, int epilogue) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % BK != 0) return 0;
+  const int ksplit = gemm_ksplit(M, N, K, epilogue);
+  return ksplit > 1 ? (long)ksplit * M * N * (long)sizeof(float) : 0;
 }
 
 // Development knob: forces the tile variant bagel_gemm_bf16 launches (tools/gemm_bench.py); -1 = automatic.

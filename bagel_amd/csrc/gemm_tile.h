@@ -15,6 +15,10 @@ struct GemmParams {
   int M, N, K;
   int tiles_m, tiles_n;
   float alpha;                 // EPI_F32_SCALED: C (fp32) = alpha * acc
+  // ksplit > 1 (gemm_bf16_nt_kernel with EPI_F32_SCALED only): workgroup (x, y) multiplies K slice y of tile x and
+  // writes its fp32 partial tile to slab y of C (slab = fp32 elements per slab, ldc = row stride inside a slab)
+  int ksplit;
+  long slab;
   // A_CONV3X3: A is an NHWC image [Hin][Win][Cin]; row m of the GEMM is output pixel (m / Wout, m % Wout),
   // K runs over (ky, kx, c); taps outside the image read `zeros`.  upsample: 0 = stride 1, padding 1;
   // 1 = the same on the 2x nearest-upsampled input; 2 = stride 2 with one zero row/column on the bottom/right.
@@ -295,14 +299,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmParams p)
 #pragma unroll
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / BK;
-  stage(0, 0);
+  int nk = p.K / BK, k_first = 0;
+  if constexpr (EPI == EPI_F32_SCALED && AMODE == A_DENSE) {
+    if (p.ksplit > 1) {   // the launcher makes every slice non-empty
+      const int per = (nk + p.ksplit - 1) / p.ksplit;
+      k_first = blockIdx.y * per;
+      nk = min(per, nk - k_first);
+      p.C = (bf16*)((float*)p.C + (long)blockIdx.y * p.slab);
+    }
+  }
+  stage(k_first, 0);
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt's LDS-DMA must have landed before the barrier publishes it (explicit: the compiler's barrier
     // fence does not reliably wait for LDS-DMA); the barrier also retires tile kt-1's buffer
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < nk) stage(k_first + kt + 1, (kt + 1) & 1);
     const char* base = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {

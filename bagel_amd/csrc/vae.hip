@@ -25,6 +25,8 @@ extern "C" int bagel_conv3x3_nhwc_bf16(const void* x, int Hin, int Win, int Cin,
   BAGEL_CHECK(upsample >= 0 && upsample <= 2, "bagel_conv3x3_nhwc_bf16: resample mode %d unknown", upsample);
   BAGEL_CHECK(upsample != 2 || (Hin % 2 == 0 && Win % 2 == 0), "bagel_conv3x3_nhwc_bf16: stride 2 needs even %dx%d", Hin, Win);
   GemmParams p;
+  p.ksplit = 1;
+  p.slab = 0;
   p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.upsample = upsample;
   p.Hout = upsample == 1 ? 2 * Hin : upsample == 2 ? Hin / 2 : Hin;
   p.Wout = upsample == 1 ? 2 * Win : upsample == 2 ? Win / 2 : Win;

@@ -85,6 +85,52 @@ def test_gemm_swiglu(M, I, K):
     _close(C, ref, ulps=3.0, what="gemm swiglu")
 
 
+@pytest.mark.parametrize("N,Kd,epi", [(3584, 3584, "residual"), (4608, 3584, "bias"), (3584, 18944, "residual"),
+                                      (1152, 4352, "bias_residual"), (4304, 1152, "bias_gelu"), (528, 320, "bias")])
+def test_gemm_split_k_mid_rows(N, Kd, epi):
+    """bagel_gemm_ws_bf16 at 65 ... 512 rows: the split-K form against the one-pass kernel and the fp32 statement, and a
+    row's bits do not depend on how many rows share the launch."""
+    k = _K()
+    g = torch.Generator(device=DEV).manual_seed(23)
+    Mmax = 512
+    X = torch.randn((Mmax, Kd), generator=g, device=DEV).to(BF16)
+    W = (torch.randn((N, Kd), generator=g, device=DEV) * 0.03).to(BF16)
+    b = torch.randn((N,), generator=g, device=DEV).to(BF16) if "bias" in epi else None
+    R = torch.randn((Mmax, N), generator=g, device=DEV).to(BF16) if "residual" in epi else None
+    code = {"bias": k.EPI_BIAS, "residual": k.EPI_RESIDUAL, "bias_residual": k.EPI_BIAS_RESIDUAL, "bias_gelu": k.EPI_BIAS_GELU}[epi]
+    need = k.gemm_workspace_bytes(Mmax, N, Kd, code)
+    ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=DEV)
+    full = torch.full((Mmax, N), float("nan"), dtype=BF16, device=DEV)
+    k.gemm(X, W, full, bias=b, residual=R, epilogue=code, workspace=ws)
+    plain = torch.empty((Mmax, N), dtype=BF16, device=DEV)
+    k.gemm(X, W, plain, bias=b, residual=R, epilogue=code)
+    if need:
+        assert not torch.equal(full, plain) or Kd <= 512   # another summation order (the split was taken)
+    acc = X.float() @ W.float().t()
+    if epi == "bias":
+        ref = (acc + b.float()).to(BF16)
+    elif epi == "residual":
+        ref = (acc.to(BF16).float() + R.float()).to(BF16)
+    elif epi == "bias_residual":
+        ref = ((acc + b.float()).to(BF16).float() + R.float()).to(BF16)
+    else:
+        ref = torch.nn.functional.gelu((acc + b.float()).to(BF16).float(), approximate="tanh").to(BF16)
+    _close(full, ref, ulps=3.0 if epi == "bias_gelu" else 2.0, what=f"split-K gemm {epi}")
+    for rows in (65, 100, 128, 300):
+        C = torch.empty((rows, N), dtype=BF16, device=DEV)
+        k.gemm(X[:rows], W, C, bias=b, residual=None if R is None else R[:rows], epilogue=code, workspace=ws)
+        assert torch.equal(C, full[:rows]), f"{rows} rows differ from the same rows of a {Mmax}-row launch"
+    # in place (the residual IS the output) and without a workspace large enough (falls back to the one-pass kernel)
+    if epi == "residual":
+        Xr = R[:200].clone()
+        k.gemm(X[:200], W, Xr, residual=Xr, epilogue=code, workspace=ws)
+        assert torch.equal(Xr, full[:200])
+    small = torch.empty((64,), dtype=torch.uint8, device=DEV)
+    C = torch.empty((200, N), dtype=BF16, device=DEV)
+    k.gemm(X[:200], W, C, bias=b, residual=None if R is None else R[:200], epilogue=code, workspace=small)
+    assert torch.equal(C, plain[:200])
+
+
 @pytest.fixture(params=["one_launch", "one_launch_registers", "split_k"])
 def skinny_form(request):
     """The forms of bagel_skinny_gemm_bf16: the one-launch MFMA kernel (default; up to 16 rows it brings the weights in

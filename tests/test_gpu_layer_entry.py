@@ -63,7 +63,7 @@ def _per_op_layer(K, w, X, Kw, Vt, cos, sin, row_cs, row_slot, tiles, n_tiles, S
             ep = {None: K.SK_BIAS, "residual": K.SK_RESIDUAL, "swiglu": K.SK_SWIGLU}[kw.pop("kind", None)]
             return K.skinny_gemm(x, wt, out, skw, epilogue=ep, **kw)
         ep = {None: K.EPI_BIAS, "residual": K.EPI_RESIDUAL, "swiglu": K.EPI_SWIGLU}[kw.pop("kind", None)]
-        return K.gemm(x, wt, out, epilogue=ep, **kw)
+        return K.gemm(x, wt, out, epilogue=ep, workspace=skw, **kw)
 
     K.rmsnorm(X, Xn, first["ln_in"], u["ln_in"], split, eps)
     if Mv:

@@ -95,6 +95,30 @@ def prefill(model, dims, dev):
             "context_tokens_per_sec": sum(kv) / dt}
 
 
+def prompt(model, dims, dev, tokens, batch=1):
+    """A text prompt's prefill alone (the context a text-to-image or a chat request builds): `tokens` ids per sample
+    through forward_cache_update_text, weights read once per layer."""
+    class Tok:
+        def encode(self, s):
+            return [int(t) for t in s.split()]
+
+    text = " ".join(str(10 + i % 1000) for i in range(tokens - 2))   # + bos and eos
+
+    def run():
+        past = NaiveCache(dims.num_layers)
+        gi, kv, rope = model.prepare_prompts([0] * batch, [0] * batch, [text] * batch, Tok(), IDS)
+        model.forward_cache_update_text(past, **gi)
+        return kv
+
+    run()
+    run()
+    kv, dt = timed(run)
+    w = model.engine.w
+    layer_bytes = sum(t.numel() * 2 for lw in w.layers for t in (lw.wqkv[1], lw.wo[1], lw.wgu[1], lw.wd[1]))
+    return {"workload": f"prompt: text prefill, {kv[0]} tokens x {batch}", "seconds": dt, "ms": dt * 1e3,
+            "tokens_per_sec": sum(kv) / dt, "weight_bytes": layer_bytes, "achieved_GBps_of_weights": layer_bytes / dt / 1e9}
+
+
 def think(model, dims, dev, max_length, batch=1, ctx=400):
     """BASELINE config 5, text half: greedy decode of max_length tokens over a ctx-token context (per sample)."""
     past = synthetic_context(dims, batch, ctx, dev, 5)
@@ -111,7 +135,8 @@ def think(model, dims, dev, max_length, batch=1, ctx=400):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("workload", choices=["edit", "prefill", "think"])
+    ap.add_argument("workload", choices=["edit", "prefill", "think", "prompt"])
+    ap.add_argument("--prompt-tokens", type=int, default=200, help="tokens per sample (prompt)")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--num-timesteps", type=int, default=50)
     ap.add_argument("--max-length", type=int, default=300)
@@ -133,6 +158,8 @@ def main():
         out = edit(model, dims, dev, args.batch, args.num_timesteps)
     elif args.workload == "prefill":
         out = prefill(model, dims, dev)
+    elif args.workload == "prompt":
+        out = prompt(model, dims, dev, args.prompt_tokens, args.decode_batch)
     else:
         if os.environ.get("DECODE_MIN_CHUNK"):   # development: keys per workgroup of the one-launch decode attention
             from bagel_amd import _lib as K
