@@ -36,7 +36,7 @@ int und_linear(const void* in, long ld_in, const void* W, void* out, long ld_out
                                   r->skinny_ws_bytes, stream);
   }
   const int ep = kind == 0 ? BAGEL_EPI_BIAS : kind == 1 ? BAGEL_EPI_RESIDUAL : BAGEL_EPI_SWIGLU;
-  // 65 ... 512 rows (a text prompt's prefill) split the reduction of the narrow projections over the chip
+  // 65 ... 1024 rows (a text prompt's prefill) split the reduction of the narrow projections over the chip
   return bagel_gemm_ws_bf16(in, ld_in, W, K, out, ld_out, n, N, K, bias, residual, ldr, ep, 1.0f, r->skinny_ws, r->skinny_ws_bytes,
                             stream);
 }

@@ -129,6 +129,20 @@ def test_gemm_split_k_mid_rows(N, Kd, epi):
     C = torch.empty((200, N), dtype=BF16, device=DEV)
     k.gemm(X[:200], W, C, bias=b, residual=None if R is None else R[:200], epilogue=code, workspace=small)
     assert torch.equal(C, plain[:200])
+    # the second row class, 513 ... 1024 rows: split only on long reductions, again the same for every row count
+    if Kd >= 8192:
+        X2 = torch.randn((1024, Kd), generator=g, device=DEV).to(BF16)
+        R2 = torch.randn((1024, N), generator=g, device=DEV).to(BF16)
+        need2 = k.gemm_workspace_bytes(1024, N, Kd, code)
+        assert need2 > 0
+        ws2 = torch.empty((need2,), dtype=torch.uint8, device=DEV)
+        full2 = torch.empty((1024, N), dtype=BF16, device=DEV)
+        k.gemm(X2, W, full2, residual=R2, epilogue=code, workspace=ws2)
+        _close(full2, ((X2.float() @ W.float().t()).to(BF16).float() + R2.float()).to(BF16), what="split-K gemm, 1024 rows")
+        C = torch.empty((700, N), dtype=BF16, device=DEV)
+        k.gemm(X2[:700], W, C, residual=R2[:700], epilogue=code, workspace=ws2)
+        assert torch.equal(C, full2[:700])
+    assert k.gemm_workspace_bytes(1025, N, Kd, code) == 0 and k.gemm_workspace_bytes(64, N, Kd, code) == 0
 
 
 @pytest.fixture(params=["one_launch", "one_launch_registers", "split_k"])
