@@ -671,7 +671,7 @@ __global__ __launch_bounds__(512) void stream_dma_kernel(const bf16* __restrict_
 #endif
 }
 
-static int g_stream_dma = 1;   // development knob: 0 keeps the register form at up to 16 rows too (bagel_set_stream_dma)
+static int g_stream_dma = 1;   // development knob: 0 keeps the register form at every row count (bagel_set_stream_dma)
 extern "C" void bagel_set_stream_dma(int on) { g_stream_dma = on; }
 
 template <int G, int RB, int S>
@@ -734,6 +734,12 @@ static void stream_launch(const bf16* X, long ldx, const bf16* W, long ldw, bf16
   if (g_stream_dma && G == 1 && !wide) {
     if (sw) stream_dma_launch_one<1, 2, 2>(X, ldx, W, ldw, C, ldc, M, N, K, bias, R, ldr, epilogue, ns, st);
     else stream_dma_launch_one<1, 1, 3>(X, ldx, W, ldw, C, ldc, M, N, K, bias, R, ldr, epilogue, ns, st);
+    return;
+  }
+  if (g_stream_dma && !sw && !wide) {   // more than 16 rows: rings + accumulators fit LDS without SwiGLU's second row block
+    if (G == 2) stream_dma_launch_one<2, 1, 3>(X, ldx, W, ldw, C, ldc, M, N, K, bias, R, ldr, epilogue, ns, st);
+    else if (G == 3) stream_dma_launch_one<3, 1, 2>(X, ldx, W, ldw, C, ldc, M, N, K, bias, R, ldr, epilogue, ns, st);
+    else stream_dma_launch_one<4, 1, 2>(X, ldx, W, ldw, C, ldc, M, N, K, bias, R, ldr, epilogue, ns, st);
     return;
   }
 #define STREAM(G_, RB_, MAXT_) stream_launch_one<G_, RB_, MAXT_>(X, ldx, W, ldw, C, ldc, M, N, K, bias, R, ldr, epilogue, ns, st)

@@ -147,8 +147,9 @@ def test_gemm_split_k_mid_rows(N, Kd, epi):
 
 @pytest.fixture(params=["one_launch", "one_launch_registers", "split_k"])
 def skinny_form(request):
-    """The forms of bagel_skinny_gemm_bf16: the one-launch MFMA kernel (default; up to 16 rows it brings the weights in
-    by LDS-DMA), the same with the weights loaded to registers at every row count, and the split-K + reduce fallback."""
+    """The forms of bagel_skinny_gemm_bf16: the one-launch MFMA kernel (default; it brings the weights in by LDS-DMA
+    where its rings fit), the same with the weights loaded to registers at every row count, and the split-K + reduce
+    fallback."""
     lib = _K().lib()
     lib.bagel_set_stream_mfma(0 if request.param == "split_k" else 1)
     lib.bagel_set_stream_dma(0 if request.param == "one_launch_registers" else 1)
@@ -198,10 +199,10 @@ def test_skinny_gemm_row_count_invariance(N, Kd, epi):
         C = torch.empty((rows, ncol), dtype=BF16, device=DEV)
         k.skinny_gemm(X[:rows], W, C, ws, bias=b, residual=None if R is None else R[:rows], epilogue=code)
         assert torch.equal(C, full[:rows]), f"{rows} rows differ from the same rows of a 64-row launch"
-    # up to 16 rows the weights come in by LDS-DMA, above that through registers: the register form at few rows, too
+    # the weights come in by LDS-DMA (SwiGLU above 16 rows and the widest projections aside): the register form, too
     k.lib().bagel_set_stream_dma(0)
     try:
-        for rows in (3, 16):
+        for rows in (3, 16, 24, 40, 64):
             C = torch.empty((rows, ncol), dtype=BF16, device=DEV)
             k.skinny_gemm(X[:rows], W, C, ws, bias=b, residual=None if R is None else R[:rows], epilogue=code)
             assert torch.equal(C, full[:rows]), f"{rows} rows (register form) differ from a 64-row launch"
