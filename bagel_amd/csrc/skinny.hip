@@ -730,7 +730,7 @@ static void stream_launch(const bf16* X, long ldx, const bf16* W, long ldw, bf16
   // order whatever shares the launch.  Their accumulators meet in LDS: ns * RB * G KiB <= 64 KiB.
   const int rb = sw ? 2 : 1;
   const int ns = stream_waves_per_block(N / (16 * rb), K / 128, 16 / rb);
-  const bool wide = M > 8 && !sw && N % 64 == 0 && N / 64 >= 8 * bagel_cu_count() && ns * 4 * G <= 64;
+  const bool wide = M > 8 && G <= 2 && !sw && N % 64 == 0 && N / 64 >= 8 * bagel_cu_count() && ns * 4 * G <= 64;
   if (g_stream_dma && G == 1 && !wide) {
     if (sw) stream_dma_launch_one<1, 2, 2>(X, ldx, W, ldw, C, ldc, M, N, K, bias, R, ldr, epilogue, ns, st);
     else stream_dma_launch_one<1, 1, 3>(X, ldx, W, ldw, C, ldc, M, N, K, bias, R, ldr, epilogue, ns, st);
