@@ -145,6 +145,15 @@ def test_gemm_split_k_mid_rows(N, Kd, epi):
     assert k.gemm_workspace_bytes(1025, N, Kd, code) == 0 and k.gemm_workspace_bytes(64, N, Kd, code) == 0
 
 
+def test_linear_entry_points_random_shapes(monkeypatch):
+    """Random row counts, widths, depths, epilogues, row strides and forms through bagel_skinny_gemm_bf16 /
+    bagel_skinny_gemv_bf16 / bagel_gemm_ws_bf16 against the fp32 statement; columns past the output stay untouched."""
+    import sys
+    from tools import fuzz_linear
+    monkeypatch.setattr(sys, "argv", ["fuzz_linear.py", "150"])
+    fuzz_linear.main()
+
+
 @pytest.fixture(params=["one_launch", "one_launch_registers", "split_k"])
 def skinny_form(request):
     """The forms of bagel_skinny_gemm_bf16: the one-launch MFMA kernel (default; it brings the weights in by LDS-DMA
