@@ -71,8 +71,10 @@ __global__ __launch_bounds__(1024) void decode_attention_kernel(DecParams p) {
   const int grp = __builtin_amdgcn_readfirstlane(tid >> 8), t256 = tid & 255, wv = (tid >> 6) & 3;
   const DecTile t = p.tiles[m];
   const int slot = p.row_slot[m];
-  // chunk length: at least min_chunk keys, at most MAX_SPLITS chunks, whole rounds of GROUPS tiles
-  const int chunk = (max(p.min_chunk, (t.kv_len + MAX_SPLITS - 1) / MAX_SPLITS) + GROUPS * TK - 1) / (GROUPS * TK) * (GROUPS * TK);
+  // chunk length: at least min_chunk keys, at most as many chunks as the grid has (MAX_SPLITS, fewer when the caller's
+  // bound on the key count sized it: a bound that is too small then costs time, not keys), whole rounds of GROUPS tiles
+  const int max_chunks = (int)gridDim.x;
+  const int chunk = (max(p.min_chunk, (t.kv_len + max_chunks - 1) / max_chunks) + GROUPS * TK - 1) / (GROUPS * TK) * (GROUPS * TK);
   const int nsplit = (t.kv_len + chunk - 1) / chunk;
   if (c >= nsplit) return;
   const int k_begin = c * chunk, k_end = min(k_begin + chunk, t.kv_len);

@@ -199,7 +199,7 @@ typedef struct bagel_mot_rows {        /* one packed forward: activations, table
  * keys of a sample split over workgroups and merged by the last one to finish.
  * workspace: bagel_decode_attention_workspace_bytes(), its first 256 bytes zero before the first call (the kernel
  * leaves them zero); calls sharing a workspace must not overlap.  max_kv_len: an upper bound of every row's kv_len
- * (sizes the grid; 0 = unknown, S is used).  Same finite-padding precondition on Vt_ws as
+ * (sizes the grid; 0 = unknown, S is used; a bound below a row's kv_len only makes that row's chunks longer).  Same finite-padding precondition on Vt_ws as
  * bagel_varlen_attention_bf16.  bagel_decode_attention_supported() != 0: rows * Hkv <= 64, Hq / Hkv 7 or 2,
  * head_dim 128 or 64. */
 int bagel_decode_attention_supported(int rows, int Hq, int Hkv, int head_dim);
