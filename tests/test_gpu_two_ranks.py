@@ -32,7 +32,9 @@ def _worker(rank, world, port, name, q):
         dist.all_gather_into_tensor = counting
         out = run_scenario_on_gpu(sc, OracleRun(sc))
         torch.cuda.synchronize()
-        q.put((rank, len(calls), [x.float().cpu() for x in out]))
+        # numpy arrays travel through the queue by value; torch tensors would be shared by file descriptor, which the
+        # parent can only collect while this process is still alive
+        q.put((rank, len(calls), [x.float().cpu().numpy() for x in out]))
     finally:
         dist.destroy_process_group()
 
@@ -59,7 +61,7 @@ def test_ranks_reproduce_one(name, world):
     for _ in range(world):
         rank, n_gathers, out = q.get(timeout=240)
         assert n_gathers == sc.num_timesteps - 1      # one exchange per Euler step
-        got[rank] = out
+        got[rank] = [torch.from_numpy(x) for x in out]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
