@@ -15,10 +15,13 @@ DEV = "cuda:0"
 BF16 = torch.bfloat16
 
 
-def close(got, ref, what):
+def close(got, ref, what, extra=None):
+    """extra: an additional per-element allowance (SwiGLU: one bf16 ulp of the gate, times the up value)."""
     g, r = got.float().cpu(), ref.float().cpu()
     assert torch.isfinite(g).all(), what
     tol = 2.0 ** -6 * r.abs().clamp(min=1.0) + 1e-2
+    if extra is not None:
+        tol = tol + extra.float().cpu()
     bad = (g - r).abs() > tol
     assert not bad.any(), (what, float((g - r).abs().max()), int(bad.sum()))
 
@@ -38,20 +41,21 @@ def main():
         else:
             M = rnd.randint(65, 1100)
             Kd = 64 * rnd.randint(1, 120)
-            epi = rnd.choice([K.EPI_BIAS, K.EPI_RESIDUAL, K.EPI_BIAS_RESIDUAL, K.EPI_BIAS_GELU])
-            N = 4 * rnd.randint(2, 1200)
+            epi = rnd.choice([K.EPI_BIAS, K.EPI_RESIDUAL, K.EPI_BIAS_RESIDUAL, K.EPI_BIAS_GELU, K.EPI_SWIGLU])
+            N = 32 * rnd.randint(1, 300) if epi == K.EPI_SWIGLU else 4 * rnd.randint(2, 1200)
             form = "ws"
         pad_x, pad_c = rnd.choice([0, 8, 64]), rnd.choice([0, 8, 32])
         g = torch.Generator(device=DEV).manual_seed(case)
         Xs = torch.randn((M, Kd + pad_x), generator=g, device=DEV).to(BF16)
         X = Xs[:, :Kd]
         W = (torch.randn((N, Kd), generator=g, device=DEV) * 0.05).to(BF16)
-        ncol = N // 2 if (which == "skinny" and epi == K.SK_SWIGLU) else N
+        ncol = N // 2 if epi == (K.SK_SWIGLU if which == "skinny" else K.EPI_SWIGLU) else N
         Cs = torch.full((M, ncol + pad_c), float("nan"), device=DEV, dtype=BF16)
         C = Cs[:, :ncol]
         b = torch.randn((N,), generator=g, device=DEV).to(BF16)
         R = torch.randn((M, ncol), generator=g, device=DEV).to(BF16)
         acc = X.float() @ W.float().t()
+        extra = None
         what = f"case {case}: {which} {form} M={M} N={N} K={Kd} epi={epi} pad_x={pad_x} pad_c={pad_c}"
         if which == "skinny":
             lib.bagel_set_stream_mfma(0 if form == "splitk" else 1)
@@ -72,6 +76,7 @@ def main():
                 a3 = acc.view(M, N // 32, 2, 16)
                 gate, up = a3[:, :, 0].reshape(M, ncol).to(BF16).float(), a3[:, :, 1].reshape(M, ncol).to(BF16).float()
                 ref = (torch.nn.functional.silu(gate).to(BF16).float() * up).to(BF16)
+                extra = 2.0 ** -7 * gate.abs().clamp(min=1.0) * up.abs()
             lib.bagel_set_stream_mfma(1)
             lib.bagel_set_stream_dma(1)
         else:
@@ -85,11 +90,17 @@ def main():
             elif epi == K.EPI_BIAS_RESIDUAL:
                 K.gemm(X, W, C, bias=b, residual=R, epilogue=epi, workspace=ws)
                 ref = ((acc + b.float()).to(BF16).float() + R.float()).to(BF16)
+            elif epi == K.EPI_SWIGLU:
+                K.gemm(X, W, C, epilogue=epi, workspace=ws)
+                a3 = acc.view(M, N // 32, 2, 16)
+                gate, up = a3[:, :, 0].reshape(M, ncol).to(BF16).float(), a3[:, :, 1].reshape(M, ncol).to(BF16).float()
+                ref = (torch.nn.functional.silu(gate).to(BF16).float() * up).to(BF16)
+                extra = 2.0 ** -7 * gate.abs().clamp(min=1.0) * up.abs()
             else:
                 K.gemm(X, W, C, bias=b, epilogue=epi, workspace=ws)
                 ref = torch.nn.functional.gelu((acc + b.float()).to(BF16).float(), approximate="tanh").to(BF16)
         torch.cuda.synchronize()
-        close(C, ref, what)
+        close(C, ref, what, extra)
         if pad_c:
             assert torch.isnan(Cs[:, ncol:].float()).all(), what + ": wrote past the output columns"
         if case % 20 == 0:
