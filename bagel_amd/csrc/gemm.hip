@@ -32,6 +32,9 @@ extern "C" void bagel_set_gemm_diag(void* buf) { g_gemm_diag = (unsigned long lo
 static int g_gemm_variant = -1;  // -1: choose by problem size
 static int g_gemm_persistent = 1;  // 0: one workgroup per output tile
 
+static int g_gemm_stages = 0;   // development knob: 0 automatic, 2 / 3 force the LDS stages of the 128 x 128 kernel
+extern "C" void bagel_set_gemm_stages(int n) { g_gemm_stages = n == 2 || n == 3 ? n : 0; }
+
 // CUs of the current device, rounded down to a multiple of the 8 XCDs (256 on MI355X)
 static int compute_units() {
   const int cu = bagel_cu_count();
@@ -43,13 +46,17 @@ static int launch_gemm(GemmParams p, int epilogue, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   const dim3 grid(p.tiles_m * p.tiles_n), block(WM * WN * 64);
-  const size_t lds = 2 * (BM + BN) * ROW_BYTES;
+  // at most one workgroup per CU: three LDS stages, so that a tile has two K steps to land
+  const bool deep = g_gemm_stages > 0 ? g_gemm_stages == 3 : p.tiles_m * p.tiles_n <= compute_units();
+  const size_t lds = (deep ? 3 : 2) * (BM + BN) * ROW_BYTES;
 #define LAUNCH(EPI)                                                                              \
   do {                                                                                           \
-    auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, EPI, A_DENSE>;                                        \
-    static BagelLdsAllowed allowed;                                                              \
-    bagel_allow_lds(allowed, (const void*)kern, (int)lds);                                       \
-    hipLaunchKernelGGL(kern, grid, block, lds, stream, p);                                       \
+    auto k2 = gemm_bf16_nt_kernel<BM, BN, WM, WN, EPI, A_DENSE, 2>;                              \
+    auto k3 = gemm_bf16_nt_kernel<BM, BN, WM, WN, EPI, A_DENSE, 3>;                              \
+    static BagelLdsAllowed allowed2, allowed3;                                                   \
+    bagel_allow_lds(allowed2, (const void*)k2, 2 * (BM + BN) * ROW_BYTES);                       \
+    bagel_allow_lds(allowed3, (const void*)k3, 3 * (BM + BN) * ROW_BYTES);                       \
+    hipLaunchKernelGGL(deep ? k3 : k2, grid, block, lds, stream, p);                             \
   } while (0)
   switch (epilogue) {
     case EPI_BIAS: LAUNCH(EPI_BIAS); break;
@@ -123,11 +130,15 @@ static int launch_gemm_splitk(GemmParams p, int epilogue, int ksplit, float* wor
   q.bias = nullptr;
   q.R = nullptr;
   const dim3 grid(p.tiles_m * p.tiles_n, ksplit), block(256);
-  const size_t lds = 2 * (128 + 128) * ROW_BYTES;
-  auto kern = gemm_bf16_nt_kernel<128, 128, 2, 2, EPI_F32_SCALED, A_DENSE>;
-  static BagelLdsAllowed allowed;
-  bagel_allow_lds(allowed, (const void*)kern, (int)lds);
-  hipLaunchKernelGGL(kern, grid, block, lds, stream, q);
+  // at most one workgroup per CU: three LDS stages (same rule as launch_gemm)
+  const bool deep = g_gemm_stages > 0 ? g_gemm_stages == 3 : (long)p.tiles_m * p.tiles_n * ksplit <= compute_units();
+  const size_t lds = (deep ? 3 : 2) * (128 + 128) * ROW_BYTES;
+  auto k2 = gemm_bf16_nt_kernel<128, 128, 2, 2, EPI_F32_SCALED, A_DENSE, 2>;
+  auto k3 = gemm_bf16_nt_kernel<128, 128, 2, 2, EPI_F32_SCALED, A_DENSE, 3>;
+  static BagelLdsAllowed allowed2, allowed3;
+  bagel_allow_lds(allowed2, (const void*)k2, 2 * (128 + 128) * ROW_BYTES);
+  bagel_allow_lds(allowed3, (const void*)k3, 3 * (128 + 128) * ROW_BYTES);
+  hipLaunchKernelGGL(deep ? k3 : k2, grid, block, lds, stream, q);
   BAGEL_LAUNCH_CHECK();
   const long quads = (long)p.M * (p.N / 4);
   hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, workspace, ksplit, q.slab,
@@ -247,6 +258,7 @@ static int gemm_entry(const void* A, long lda, const void* W, long ldw, void* C,
     case 5: return launch_pipelined<288, 4>(p, epilogue, (hipStream_t)stream);
     case 6: return launch_pipelined<256, 4>(p, epilogue, (hipStream_t)stream);
     case 0: return launch_gemm<128, 128, 2, 2>(p, epilogue, (hipStream_t)stream);
+    case 8: return launch_gemm<64, 128, 2, 2>(p, epilogue, (hipStream_t)stream);
     default: bagel_set_error("bagel_gemm_bf16: unknown tile variant %d", variant); return 1;
   }
 }

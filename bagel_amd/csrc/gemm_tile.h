@@ -201,8 +201,12 @@ __device__ __forceinline__ bool gemm_epilogue(const GemmParams& p, const f32x4 (
   return wide && m_base + FM * 16 <= p.M;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int AMODE>
+// NS: LDS stages.  2: tile kt+1 is requested when tile kt is published and has one K step to land - enough when two
+// workgroups share a CU and cover each other.  3: tile kt+2 is requested at that point, for launches that leave a CU
+// one workgroup (few tiles, split-K), where a K step otherwise lasts one memory round trip.
+template <int BM, int BN, int WM, int WN, int EPI, int AMODE, int NS = 2>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmParams p) {
+  static_assert(NS == 2 || NS == 3, "two or three LDS stages");
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;  // per-wave tile
   constexpr int FM = TM / 16, FN = TN / 16;  // 16x16 fragments per wave
@@ -309,13 +313,26 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmParams p)
     }
   }
   stage(k_first, 0);
+  if (NS == 3 && nk > 1) stage(k_first + 1, 1);
+  int buf = 0;
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt's LDS-DMA must have landed before the barrier publishes it (explicit: the compiler's barrier
     // fence does not reliably wait for LDS-DMA); the barrier also retires tile kt-1's buffer
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage(k_first + kt + 1, (kt + 1) & 1);
-    const char* base = smem + (kt & 1) * STAGE_BYTES;
+    if constexpr (NS == 3) {
+      // tile kt+1 may still be in flight: wait for all but its pieces.  The bare barrier instruction: __syncthreads()
+      // carries a fence, which drains the counter and with it the request that should stay in flight.
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(A_ITERS + W_ITERS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (kt + NS - 1 < nk) stage(k_first + kt + NS - 1, NS == 3 ? (buf == 0 ? 2 : buf - 1) : (kt + 1) & 1);
+    const char* base = smem + buf * STAGE_BYTES;
+    buf = buf + 1 == NS ? 0 : buf + 1;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 af[FM], wf[FN];

@@ -18,6 +18,10 @@ SHAPES = [("qkv", 4608, 3584, K.EPI_BIAS), ("o_proj", 3584, 3584, K.EPI_RESIDUAL
 
 def main():
     dev = "cuda:0"
+    if os.environ.get("STAGES"):    # development: LDS stages of the 128 x 128 kernel
+        K.lib().bagel_set_gemm_stages(int(os.environ["STAGES"]))
+    if os.environ.get("VARIANT"):   # development: force a tile variant of bagel_gemm_bf16 (disables the split-K form)
+        K.lib().bagel_set_gemm_variant(int(os.environ["VARIANT"]))
     for M in [int(v) for v in sys.argv[1:]] or [96, 128, 256, 512, 1024, 2048]:
         tot = 0.0
         line = []
