@@ -258,7 +258,7 @@ static int gemm_entry(const void* A, long lda, const void* W, long ldw, void* C,
     case 5: return launch_pipelined<288, 4>(p, epilogue, (hipStream_t)stream);
     case 6: return launch_pipelined<256, 4>(p, epilogue, (hipStream_t)stream);
     case 0: return launch_gemm<128, 128, 2, 2>(p, epilogue, (hipStream_t)stream);
-    case 8: return launch_gemm<64, 128, 2, 2>(p, epilogue, (hipStream_t)stream);
+    case 8: return launch_gemm<64, 128, 2, 2>(p, epilogue, (hipStream_t)stream);   // never chosen automatically (tools/midm_bench.py)
     default: bagel_set_error("bagel_gemm_bf16: unknown tile variant %d", variant); return 1;
   }
 }

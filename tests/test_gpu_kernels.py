@@ -542,7 +542,7 @@ def test_error_reporting():
         k.gemm(A, A, torch.zeros((8, 8), dtype=BF16, device=DEV))
 
 
-@pytest.mark.parametrize("variant", [0, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 3, 4, 5, 6, 8])
 @pytest.mark.parametrize("M,N,K,epi", [(700, 512, 256, "bias"), (512, 768, 1024, "residual"), (300, 1024, 192, "swiglu"),
                                        (4096, 4608, 3584, "bias"), (256, 256, 64, "bias"), (260, 256, 128, "residual"),
                                        (1024, 3584, 512, "residual"), (520, 228, 64, "bias")])
@@ -582,6 +582,26 @@ def test_gemm_tile_variants(variant, M, N, K, epi):
     finally:
         lib.bagel_set_gemm_variant(-1)
     _close(C, ref, ulps=3.0, what=f"variant {variant} {epi}")
+
+
+@pytest.mark.parametrize("M,N,Kd", [(200, 1152, 4352), (1000, 3584, 3584), (96, 64, 3584), (4098, 3584, 64)])
+def test_gemm_lds_stages_are_invisible(M, N, Kd):
+    """The 128 x 128 tile kernel with two and with three LDS stages walks the same K steps in the same order."""
+    k = _K()
+    X, W, b = _rand((M, Kd), 1.0, 70).to(DEV), _rand((N, Kd), 0.03, 71).to(DEV), _rand((N,), 0.5, 72).to(DEV)
+    out = {}
+    try:
+        k.lib().bagel_set_gemm_variant(0)
+        for stages in (2, 3):
+            k.lib().bagel_set_gemm_stages(stages)
+            C = torch.full((M, N), float("nan"), dtype=BF16, device=DEV)
+            k.gemm(X, W, C, bias=b)
+            out[stages] = C
+    finally:
+        k.lib().bagel_set_gemm_stages(0)
+        k.lib().bagel_set_gemm_variant(-1)
+    assert torch.equal(out[2], out[3])
+    _close(out[3], (X.float() @ W.float().t() + b.float()).to(BF16), what="three-stage tile kernel")
 
 
 @pytest.mark.parametrize("variant", [3, 4, 5, 6])
