@@ -34,6 +34,8 @@ struct DecTile {   // same 32-byte record as the tiled kernel's table
 };
 
 constexpr int MAX_SPLITS = 64;   // key chunks per sample (grid.x)
+constexpr int MAX_TICKETS = 256;  // samples x kv heads per launch (64 samples at four kv heads)
+constexpr int TICKET_BYTES = MAX_TICKETS * 4;
 constexpr int TK = 64;           // keys per tile
 
 struct DecParams {
@@ -324,11 +326,11 @@ extern "C" void bagel_set_decode_min_chunk(int keys) { g_decode_min_chunk = keys
 extern "C" long bagel_decode_attention_workspace_bytes(int rows, int Hq, int Hkv, int head_dim) {
   if (rows <= 0 || Hq <= 0 || Hkv <= 0 || head_dim <= 0) return 0;
   const long part = (long)rows * Hkv * MAX_SPLITS * (Hq / Hkv) * (head_dim + 2) * 4;
-  return 256 + (part + 255) / 256 * 256;   // tickets (first 256 bytes hold at most 64 of them) + partials
+  return TICKET_BYTES + (part + 255) / 256 * 256;   // tickets (one per sample and kv head) + partials
 }
 
 extern "C" int bagel_decode_attention_supported(int rows, int Hq, int Hkv, int head_dim) {
-  if (rows <= 0 || Hkv <= 0 || Hq % Hkv != 0 || (long)rows * Hkv > 64) return 0;
+  if (rows <= 0 || Hkv <= 0 || Hq % Hkv != 0 || (long)rows * Hkv > MAX_TICKETS) return 0;
   const int rep = Hq / Hkv;
   return (head_dim == 128 || head_dim == 64) && (rep == 7 || rep == 2);
 }
@@ -341,7 +343,7 @@ extern "C" int bagel_decode_attention_bf16(const void* qkv, long ld, int rows, i
   BAGEL_CHECK(qkv && q_norm && k_norm && cos_table && sin_table && row_cs && row_slot && tiles && K_ws && Vt_ws && O && workspace,
               "bagel_decode_attention_bf16: null operand");
   BAGEL_CHECK(bagel_decode_attention_supported(rows, Hq, Hkv, head_dim),
-              "bagel_decode_attention_bf16: rows=%d Hq=%d Hkv=%d head_dim=%d not supported (rows * Hkv <= 64, 7 or 2 query heads "
+              "bagel_decode_attention_bf16: rows=%d Hq=%d Hkv=%d head_dim=%d not supported (rows * Hkv <= 256, 7 or 2 query heads "
               "per kv head, head_dim 128 or 64)", rows, Hq, Hkv, head_dim);
   BAGEL_CHECK(ld % 8 == 0 && ld >= (long)(Hq + 2 * Hkv) * head_dim, "bagel_decode_attention_bf16: bad leading dim");
   BAGEL_CHECK(S > 0 && S % 64 == 0, "bagel_decode_attention_bf16: S=%ld must be a positive multiple of 64", S);
@@ -355,7 +357,7 @@ extern "C" int bagel_decode_attention_bf16(const void* qkv, long ld, int rows, i
   p.cos_t = (const bf16*)cos_table; p.sin_t = (const bf16*)sin_table;
   p.row_cs = (const int*)row_cs; p.row_slot = (const int*)row_slot; p.tiles = (const DecTile*)tiles;
   p.K = (bf16*)K_ws; p.Vt = (bf16*)Vt_ws; p.O = (bf16*)O;
-  p.tickets = (unsigned*)workspace; p.part = (float*)((char*)workspace + 256);
+  p.tickets = (unsigned*)workspace; p.part = (float*)((char*)workspace + TICKET_BYTES);
   p.S = S; p.Hq = Hq; p.Hkv = Hkv; p.eps = eps; p.und_rounding = und_rounding;
   p.scale_log2 = 1.4426950408889634f / sqrtf((float)head_dim);
   // no sample has more keys than the caller's bound (or than the workspace has slots), which bounds the chunks any of

@@ -611,7 +611,7 @@ class MoTEngine:
         dws = None
         if K.decode_attention_supported(B, Hq, Hkv, D):
             dws = self._get("attn_ws_dec", (K.decode_attention_workspace_bytes(B, Hq, Hkv, D),), dtype=torch.uint8, zero=True)
-            dws[:256].zero_()   # the tickets: zero by contract; re-established here in case an earlier call was cut short
+            dws[:1024].zero_()   # the tickets: zero by contract; re-established here in case an earlier call was cut short
         rows = K.mot_rows(0, B, X, Xn, QKV, Q, O, Hm, cos, sin, row_cs[0], row_slot[0], tiles[0], B, S, skw, und_rounding=True,
                           decode_ws=dws, decode_max_kv=max(ctx_lens) + max_length)
         cs0, slot0, tile0 = row_cs.data_ptr(), row_slot.data_ptr(), tiles.data_ptr()

@@ -197,10 +197,10 @@ typedef struct bagel_mot_rows {        /* one packed forward: activations, table
  * slot included), O[i] = result.  Equivalent to bagel_qk_norm_rope_kv_bf16 + bagel_varlen_attention_bf16 on rows that
  * are each one sample's single new token (Bagel.generate_text, bagel.py:1551-1587; qwen2_navit.py:549-599), with the
  * keys of a sample split over workgroups and merged by the last one to finish.
- * workspace: bagel_decode_attention_workspace_bytes(), its first 256 bytes zero before the first call (the kernel
+ * workspace: bagel_decode_attention_workspace_bytes(), its first 1024 bytes zero before the first call (the kernel
  * leaves them zero); calls sharing a workspace must not overlap.  max_kv_len: an upper bound of every row's kv_len
  * (sizes the grid; 0 = unknown, S is used; a bound below a row's kv_len only makes that row's chunks longer).  Same finite-padding precondition on Vt_ws as
- * bagel_varlen_attention_bf16.  bagel_decode_attention_supported() != 0: rows * Hkv <= 64, Hq / Hkv 7 or 2,
+ * bagel_varlen_attention_bf16.  bagel_decode_attention_supported() != 0: rows * Hkv <= 256, Hq / Hkv 7 or 2,
  * head_dim 128 or 64. */
 int bagel_decode_attention_supported(int rows, int Hq, int Hkv, int head_dim);
 long bagel_decode_attention_workspace_bytes(int rows, int Hq, int Hkv, int head_dim);
