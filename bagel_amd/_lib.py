@@ -153,7 +153,7 @@ def gemm_workspace_bytes(M, N, K, epilogue=EPI_BIAS):
 
 def gemm(A, W, C, bias=None, residual=None, epilogue=EPI_BIAS, M=None, alpha=1.0, workspace=None):
     """C[M,N] = epilogue(A[M,K] @ W[N,K]^T) (bf16 2-D tensors, rows may be strided).  workspace: a tensor the split-K
-    form may use at 65 ... 1024 rows (bagel_gemm_ws_bf16)."""
+    form may use at 17 ... 1024 rows (bagel_gemm_ws_bf16)."""
     M = A.shape[0] if M is None else M
     N, K = W.shape
     assert A.dtype == W.dtype == torch.bfloat16 and A.shape[1] == K

@@ -73,7 +73,7 @@ static int launch_gemm(GemmParams p, int epilogue, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Split-K for row counts between the weight-streaming kernels and a chip-filling tile count (65 ... 1024 rows of a
+// Split-K for row counts between the weight-streaming kernels and a chip-filling tile count (17 ... 1024 rows of a
 // projection with few column tiles: a text prompt's prefill).  One 128 x 128 tile per 128 output features is 28-36
 // workgroups walking the whole reduction one after the other; K slices put SPLIT times as many on the chip, their fp32
 // partial tiles go through a workspace, and a second launch adds them in slice order and applies the epilogue.
@@ -81,11 +81,11 @@ static int launch_gemm(GemmParams p, int epilogue, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 constexpr int SPLITK_MAX_ROWS = 1024;
 
-// Row counts fall into two classes, (64, 512] and (512, 1024]; inside a class the split is the same for every M.
+// Row counts fall into two classes, (16, 512] and (512, 1024]; inside a class the split is the same for every M.
 // Above 512 rows only long reductions are split (slices stay at least 32 K steps deep: the down projection), because
 // the partial tiles then cost as much traffic as the weights; above 1024 rows the split measured slower.
 static int gemm_ksplit(int M, int N, int K, int epilogue) {
-  if (M <= 64 || M > SPLITK_MAX_ROWS) return 1;
+  if (M <= 16 || M > SPLITK_MAX_ROWS) return 1;
   if (epilogue != EPI_BIAS && epilogue != EPI_RESIDUAL && epilogue != EPI_BIAS_RESIDUAL && epilogue != EPI_BIAS_GELU) return 1;
   const int tiles_n = (N + 127) / 128, nk = K / BK;
   const int row_class = M <= 512 ? 1 : 2;

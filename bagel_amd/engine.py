@@ -623,8 +623,13 @@ class MoTEngine:
             # weight-streaming kernels that consume them; q/k norm, RoPE, KV write and attention are one kernel); more: o_proj / down_proj reduce their partial sums, add the
             # residual and apply the RMSNorm that follows in one launch
             K.mot_forward(self._cdims, table, n_layers, rows, kws, vtws)
-            # final norm + lm_head in one weight-streaming launch
-            K.skinny_gemm_rmsnorm_in(X, w.norm[1], eps, w.lm_head, logits, skw, Xn=Xn)
+            # final norm + lm_head in one weight-streaming launch; above 16 samples the tile kernel (every token-row
+            # fragment shared through LDS) is ahead of streaming, as in the layers
+            if B > 16:
+                K.rmsnorm(X, Xn, w.norm[1], w.norm[1], B, eps)
+                K.gemm(Xn, w.lm_head, logits)
+            else:
+                K.skinny_gemm_rmsnorm_in(X, w.norm[1], eps, w.lm_head, logits, skw, Xn=Xn)
             if logits_trace is not None:
                 logits_trace.append(logits.clone())
             if sample_fn is None:

@@ -36,11 +36,11 @@ const char* bagel_last_error(void);
 int bagel_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
                     const void* bias, const void* residual, long ldr, int epilogue, float alpha, void* stream);
 
-/* The same product for callers that own a workspace.  65 ... 1024 rows against a projection of few output features
+/* The same product for callers that own a workspace.  17 ... 1024 rows against a projection of few output features
  * (the understanding expert's q/k/v, o and down projections during a text prompt's prefill, qwen2_navit.py:541-547,
  * 605, 833) are too few tiles to fill the chip: the reduction is then split over workgroups, the fp32 partial tiles go
  * through the workspace and a second launch adds them in slice order and applies the epilogue (bias, residual,
- * bias + residual, bias + GELU).  The split depends on (N, K) and on the row class, (64, 512] or (512, 1024], only.  With a null or too small workspace, and for every
+ * bias + residual, bias + GELU).  The split depends on (N, K) and on the row class, (16, 512] or (512, 1024], only.  With a null or too small workspace, and for every
  * other shape, this is bagel_gemm_bf16.  bagel_gemm_workspace_bytes: bytes the split form needs (0 = not used). */
 int bagel_gemm_ws_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
                        const void* bias, const void* residual, long ldr, int epilogue, float alpha, void* workspace,

@@ -88,7 +88,7 @@ def test_gemm_swiglu(M, I, K):
 @pytest.mark.parametrize("N,Kd,epi", [(3584, 3584, "residual"), (4608, 3584, "bias"), (3584, 18944, "residual"),
                                       (1152, 4352, "bias_residual"), (4304, 1152, "bias_gelu"), (528, 320, "bias")])
 def test_gemm_split_k_mid_rows(N, Kd, epi):
-    """bagel_gemm_ws_bf16 at 65 ... 512 rows: the split-K form against the one-pass kernel and the fp32 statement, and a
+    """bagel_gemm_ws_bf16 at 17 ... 512 rows: the split-K form against the one-pass kernel and the fp32 statement, and a
     row's bits do not depend on how many rows share the launch."""
     k = _K()
     g = torch.Generator(device=DEV).manual_seed(23)
@@ -116,7 +116,7 @@ def test_gemm_split_k_mid_rows(N, Kd, epi):
     else:
         ref = torch.nn.functional.gelu((acc + b.float()).to(BF16).float(), approximate="tanh").to(BF16)
     _close(full, ref, ulps=3.0 if epi == "bias_gelu" else 2.0, what=f"split-K gemm {epi}")
-    for rows in (65, 100, 128, 300):
+    for rows in (17, 33, 65, 100, 128, 300):
         C = torch.empty((rows, N), dtype=BF16, device=DEV)
         k.gemm(X[:rows], W, C, bias=b, residual=None if R is None else R[:rows], epilogue=code, workspace=ws)
         assert torch.equal(C, full[:rows]), f"{rows} rows differ from the same rows of a {Mmax}-row launch"
@@ -142,7 +142,7 @@ def test_gemm_split_k_mid_rows(N, Kd, epi):
         C = torch.empty((700, N), dtype=BF16, device=DEV)
         k.gemm(X2[:700], W, C, residual=R2[:700], epilogue=code, workspace=ws2)
         assert torch.equal(C, full2[:700])
-    assert k.gemm_workspace_bytes(1025, N, Kd, code) == 0 and k.gemm_workspace_bytes(64, N, Kd, code) == 0
+    assert k.gemm_workspace_bytes(1025, N, Kd, code) == 0 and k.gemm_workspace_bytes(16, N, Kd, code) == 0
 
 
 def test_linear_entry_points_random_shapes(monkeypatch):
