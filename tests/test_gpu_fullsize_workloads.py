@@ -240,3 +240,41 @@ def test_think_then_generate(full):
         for k in ra:
             assert torch.equal(ra[k], rb[k]), k
     assert torch.equal(ta[0]["v_img"], ta[0]["v_cond"])      # same context, same RoPE position -> same velocity
+
+@pytest.mark.parametrize("batch", [6, 20])
+def test_batched_decode_matches_single_sample_logits(full, batch):
+    """Greedy decode of several samples at once (6: weight streaming; 20: the tile kernels and the tile-GEMM vocabulary
+    projection): twice identical, and every sample's first-step logits equal - within bf16 accumulation-order noise -
+    the logits the sample gets when decoded alone; identical contexts give identical rows."""
+    from bench import synthetic_context
+    from bagel_amd.modeling import NaiveCache
+    model, _, dims = full
+    dev = torch.device(DEV)
+    w = model.engine.w
+    if w.lm_head is None or w.lm_head.shape[0] != 4096:
+        gen = torch.Generator(device=dev).manual_seed(5)
+        w.lm_head = torch.empty((4096, dims.hidden_size), device=dev, dtype=BF16).normal_(0, 0.02, generator=gen)
+        w.embed_tokens = torch.empty((4096, dims.hidden_size), device=dev, dtype=BF16).normal_(0, 0.02, generator=gen)
+    ctx = 120
+    one = synthetic_context(dims, 1, ctx, dev, 9)
+    gi1 = model.prepare_start_tokens([ctx], [ctx], IDS)
+    l1 = []
+    model.generate_text(past_key_values=one, max_length=3, do_sample=False, logits_trace=l1, **gi1)
+    many = NaiveCache(dims.num_layers)
+    for l in range(dims.num_layers):
+        many.key_cache[l] = torch.cat([one.key_cache[l]] * batch)
+        many.value_cache[l] = torch.cat([one.value_cache[l]] * batch)
+    gib = model.prepare_start_tokens([ctx] * batch, [ctx] * batch, IDS)
+    la, lb = [], []
+    ta = model.generate_text(past_key_values=many, max_length=12, do_sample=False, logits_trace=la, **gib)
+    tb = model.generate_text(past_key_values=many, max_length=12, do_sample=False, logits_trace=lb, **gib)
+    assert ta.shape == (12, batch) and torch.equal(ta, tb)
+    assert all(torch.equal(x, y) and torch.isfinite(x.float()).all() for x, y in zip(la, lb))
+    first = la[0].float()
+    assert all(torch.equal(la[0][0], la[0][b]) for b in range(1, batch))      # the same context in every slot
+    ref = l1[0].float()[0]
+    # 28 layers of bf16 activations through a different kernel form (other summation orders): a few ulps of the largest logit
+    err = float((first[0] - ref).abs().max())
+    cos = float(torch.dot(first[0], ref) / (first[0].norm() * ref.norm()))
+    print(f"batch {batch}: first-step logits vs the sample alone: max-abs {err:.4f}, cosine {cos:.6f}")
+    assert err <= 2.0 ** -4 * float(ref.abs().max()) and cos >= 0.999, (err, cos)
