@@ -31,9 +31,10 @@ int und_linear(const void* in, long ld_in, const void* W, void* out, long ld_out
                const void* residual, long ldr, int kind /* 0 bias, 1 residual, 2 swiglu */, const bagel_mot_rows* r,
                void* stream) {
   // Up to 64 rows stream the weights once, with bits that do not depend on the row count (the text rows of a packed
-  // generation step rely on it).  A decode step of more than 16 samples makes no such promise across batch sizes and
-  // takes the tile kernels, which share every token-row fragment through LDS: 186 against 282 us per layer at 64 rows.
-  const bool decode_tiles = r->decode_ws != nullptr && r->rows_gen == 0 && n > 16;
+  // generation step rely on it).  A forward without generation rows (a prompt's prefill, a decode step) of more than 16
+  // rows takes the tile kernels, which share every token-row fragment through LDS: 186 against 282 us per layer at 64
+  // rows; its bits then depend on the row class (17 ... 512, 513 ... 1024, more), not on the row count inside it.
+  const bool decode_tiles = r->rows_gen == 0 && n > 16;
   if (n <= 64 && !decode_tiles) {
     const int ep = kind == 0 ? BAGEL_SK_BIAS : kind == 1 ? BAGEL_SK_RESIDUAL : BAGEL_SK_SWIGLU;
     return bagel_skinny_gemm_bf16(in, ld_in, W, K, out, ld_out, n, N, K, bias, residual, ldr, ep, r->skinny_ws,
@@ -93,7 +94,7 @@ extern "C" int bagel_mot_layer_forward(const bagel_mot_dims* d, const bagel_mot_
   const void* kn_a = Mv ? g.k_norm : u.k_norm;
   const int split = Mv ? Mv : M;
   // few understanding rows and nothing else: reduce + residual + the following RMSNorm share one launch
-  const bool fuse_norm = Mv == 0 && Mt <= 64 && H <= 8192 && !(r->decode_ws != nullptr && Mt > 16);   // und_linear() explains the exception
+  const bool fuse_norm = Mv == 0 && Mt <= 16 && H <= 8192;   // und_linear() explains the exception
   void* X_u = at(r->X, Mv, H);
   void* Xn_u = at(r->Xn, Mv, H);
 
