@@ -370,6 +370,26 @@ def test_varlen_attention(q_lens, ctx_lens, Hq, Hkv, form):
     _close(got, ref, ulps=2.0, what="attention")
 
 
+def test_varlen_attention_random_cases():
+    """Random sample counts, query and context lengths (ragged tiles, one-row tiles, contexts shorter and longer than a
+    key tile), head counts, head widths, masks and kernel forms against the checker's attention."""
+    import random
+    rnd = random.Random(11)
+    for case in range(24):
+        n = rnd.randint(1, 4)
+        q_lens = [rnd.choice([1, 2, 31, 64, 65, 127, 128, 129, 200, 300]) for _ in range(n)]
+        ctx_lens = [rnd.choice([0, 1, 7, 63, 64, 65, 130, 500]) for _ in range(n)]
+        Hkv = rnd.choice([1, 2])
+        Hq = Hkv * rnd.choice([1, 2, 7])
+        D = rnd.choice([64, 128])
+        causal = rnd.random() < 0.4
+        form = rnd.choice([0, 1])
+        got, ref = _attention_case(q_lens, ctx_lens, Hq, Hkv, seed=100 + case, causal=causal, D=D, form=form)
+        what = f"case {case}: q {q_lens} ctx {ctx_lens} Hq {Hq} Hkv {Hkv} D {D} causal {causal} form {form}"
+        assert not torch.isnan(got.float()).any(), what
+        _close(got, ref, ulps=2.0, what=what)
+
+
 @pytest.mark.parametrize("q_lens,ctx_lens,Hq,Hkv", [([34], [0], 2, 1), ([5, 200], [0, 77], 4, 2), ([300], [130], 14, 2)])
 @pytest.mark.parametrize("form", [0, 1])
 def test_varlen_attention_causal(q_lens, ctx_lens, Hq, Hkv, form):
