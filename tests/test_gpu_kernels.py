@@ -145,6 +145,51 @@ def test_gemm_split_k_mid_rows(N, Kd, epi):
     assert k.gemm_workspace_bytes(1025, N, Kd, code) == 0 and k.gemm_workspace_bytes(16, N, Kd, code) == 0
 
 
+def test_gemm_random_shapes():
+    """bagel_gemm_bf16 with the launcher's own tile choice over random row counts (ragged last tiles in both directions),
+    widths, depths and every epilogue, against an fp32 product on the device."""
+    import random
+    k = _K()
+    rnd = random.Random(5)
+    for case in range(30):
+        M = rnd.choice([1, 7, 130, 255, 257, 1000, 4098, 6001, 12294])
+        Kd = 64 * rnd.randint(1, 40)
+        epi = rnd.choice(["bias", "residual", "swiglu", "bias_residual", "f32", "bias_gelu"])
+        N = 32 * rnd.randint(1, 150) if epi == "swiglu" else 4 * rnd.randint(1, 1300)
+        g = torch.Generator(device=DEV).manual_seed(200 + case)
+        X = torch.randn((M, Kd), generator=g, device=DEV).to(BF16)
+        W = (torch.randn((N, Kd), generator=g, device=DEV) * 0.05).to(BF16)
+        b = torch.randn((N,), generator=g, device=DEV).to(BF16)
+        ncol = N // 2 if epi == "swiglu" else N
+        R = torch.randn((M, ncol), generator=g, device=DEV).to(BF16)
+        acc = X.float() @ W.float().t()
+        what = f"case {case}: M={M} N={N} K={Kd} {epi}"
+        if epi == "f32":
+            C = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+            k.gemm(X, W, C, epilogue=k.EPI_F32_SCALED, alpha=0.25)
+            assert torch.allclose(C, 0.25 * acc, rtol=1e-4, atol=1e-3), what
+            continue
+        C = torch.full((M, ncol), float("nan"), dtype=BF16, device=DEV)
+        if epi == "bias":
+            k.gemm(X, W, C, bias=b)
+            ref = (acc + b.float()).to(BF16)
+        elif epi == "residual":
+            k.gemm(X, W, C, residual=R, epilogue=k.EPI_RESIDUAL)
+            ref = (acc.to(BF16).float() + R.float()).to(BF16)
+        elif epi == "bias_residual":
+            k.gemm(X, W, C, bias=b, residual=R, epilogue=k.EPI_BIAS_RESIDUAL)
+            ref = ((acc + b.float()).to(BF16).float() + R.float()).to(BF16)
+        elif epi == "bias_gelu":
+            k.gemm(X, W, C, bias=b, epilogue=k.EPI_BIAS_GELU)
+            ref = torch.nn.functional.gelu((acc + b.float()).to(BF16).float(), approximate="tanh").to(BF16)
+        else:
+            k.gemm(X, W, C, epilogue=k.EPI_SWIGLU)
+            a3 = acc.view(M, N // 32, 2, 16)
+            gate, up = a3[:, :, 0].reshape(M, ncol).to(BF16).float(), a3[:, :, 1].reshape(M, ncol).to(BF16).float()
+            ref = (torch.nn.functional.silu(gate).to(BF16).float() * up).to(BF16)
+        _close(C, ref, ulps=4.0 if epi in ("swiglu", "bias_gelu") else 2.0, what=what)
+
+
 def test_linear_entry_points_random_shapes(monkeypatch):
     """Random row counts, widths, depths, epilogues, row strides and forms through bagel_skinny_gemm_bf16 /
     bagel_skinny_gemv_bf16 / bagel_gemm_ws_bf16 against the fp32 statement; columns past the output stay untouched."""
