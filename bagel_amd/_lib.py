@@ -171,6 +171,18 @@ def gemm(A, W, C, bias=None, residual=None, epilogue=EPI_BIAS, M=None, alpha=1.0
     return C
 
 
+def gemm_residual_rmsnorm(A, W, C, residual, norm_weight, Xn, eps, workspace):
+    """C = residual + A @ W^T and Xn = RMSNorm(C) * norm_weight (bagel_gemm_ws_residual_rmsnorm_bf16)."""
+    M, K = A.shape
+    N = W.shape[0]
+    _check(lib().bagel_gemm_ws_residual_rmsnorm_bf16(_p(A), L(A.stride(0)), _p(W), L(W.stride(0)), _p(C), L(C.stride(0)), I(M), I(N),
+                                                     I(K), _p(residual), L(residual.stride(0)), _p(norm_weight), _p(Xn),
+                                                     L(Xn.stride(0)), F(eps), _p(workspace),
+                                                     L(workspace.numel() * workspace.element_size()), _stream()),
+           "bagel_gemm_ws_residual_rmsnorm_bf16")
+    return C
+
+
 def skinny_workspace_bytes(M, N):
     return lib().bagel_skinny_gemm_workspace_bytes(I(M), I(N))
 

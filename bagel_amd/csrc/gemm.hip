@@ -118,7 +118,12 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
   *(bf16x4*)(C + (long)m * ldc + n) = o;
 }
 
-static int launch_gemm_splitk(GemmParams p, int epilogue, int ksplit, float* workspace, hipStream_t stream) {
+bool bagel_launch_reduce_residual_rmsnorm(const float* part, int slices, int M, int N, const bf16* R, long ldr, bf16* C, long ldc,
+                                          const bf16* norm_w, bf16* Xn, long ldn, float eps, hipStream_t st);   // skinny.hip
+
+// norm_w != nullptr (residual epilogue only): the reduce launch also applies the RMSNorm that follows, Xn = norm(C)
+static int launch_gemm_splitk(GemmParams p, int epilogue, int ksplit, float* workspace, hipStream_t stream,
+                              const bf16* norm_w = nullptr, bf16* Xn = nullptr, long ldn = 0, float eps = 0.f) {
   p.tiles_m = (p.M + 127) / 128;
   p.tiles_n = (p.N + 127) / 128;
   GemmParams q = p;
@@ -140,6 +145,12 @@ static int launch_gemm_splitk(GemmParams p, int epilogue, int ksplit, float* wor
   bagel_allow_lds(allowed3, (const void*)k3, 3 * (128 + 128) * ROW_BYTES);
   hipLaunchKernelGGL(deep ? k3 : k2, grid, block, lds, stream, q);
   BAGEL_LAUNCH_CHECK();
+  if (norm_w != nullptr) {
+    const bool ok = bagel_launch_reduce_residual_rmsnorm(workspace, ksplit, p.M, p.N, p.R, p.ldr, p.C, p.ldc, norm_w, Xn, ldn, eps, stream);
+    BAGEL_CHECK(ok, "bagel_gemm_ws_residual_rmsnorm_bf16: shape outside the fused reduce's limits");
+    BAGEL_LAUNCH_CHECK();
+    return 0;
+  }
   const long quads = (long)p.M * (p.N / 4);
   hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, workspace, ksplit, q.slab,
                      p.M, p.N, p.bias, p.R, p.ldr, p.C, p.ldc, epilogue);
@@ -275,6 +286,40 @@ extern "C" int bagel_gemm_ws_bf16(const void* A, long lda, const void* W, long l
                                   int K, const void* bias, const void* residual, long ldr, int epilogue,
                                   float alpha, void* workspace, long workspace_bytes, void* stream) {
   return gemm_entry(A, lda, W, ldw, C, ldc, M, N, K, bias, residual, ldr, epilogue, alpha, workspace, workspace_bytes, stream);
+}
+
+extern "C" int bagel_rmsnorm_bf16(const void* x, long ldx, void* out, long ldo, int rows, int H, const void* w_first,
+                                  const void* w_second, int split_row, float eps, void* stream);
+
+// C = bf16(bf16(A . W^T) + R) and Xn = RMSNorm(C) * norm_weight.  Where bagel_gemm_ws_bf16 would split the reduction
+// (and N <= 8192), the launch that adds the partial tiles applies the residual and the norm as well; otherwise this is
+// bagel_gemm_ws_bf16 followed by bagel_rmsnorm_bf16.
+extern "C" int bagel_gemm_ws_residual_rmsnorm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M,
+                                                   int N, int K, const void* residual, long ldr, const void* norm_weight,
+                                                   void* Xn, long ldn, float eps, void* workspace, long workspace_bytes,
+                                                   void* stream) {
+  BAGEL_CHECK(A && W && C && residual && norm_weight && Xn, "bagel_gemm_ws_residual_rmsnorm_bf16: null operand");
+  BAGEL_CHECK(M > 0 && N > 0 && K > 0 && K % BK == 0 && N % 4 == 0, "bagel_gemm_ws_residual_rmsnorm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
+  const int ksplit = g_gemm_variant < 0 ? gemm_ksplit(M, N, K, EPI_RESIDUAL) : 1;
+  const bool fused = ksplit > 1 && ksplit <= 16 && N <= 8192 && workspace != nullptr && (uintptr_t)workspace % 16 == 0 &&
+                     (long)ksplit * M * N * (long)sizeof(float) <= workspace_bytes && lda >= K && ldw >= K && lda % 8 == 0 &&
+                     ldw % 8 == 0 && ((uintptr_t)A | (uintptr_t)W) % 16 == 0;
+  if (!fused) {
+    const int rc = gemm_entry(A, lda, W, ldw, C, ldc, M, N, K, nullptr, residual, ldr, EPI_RESIDUAL, 1.0f, workspace, workspace_bytes, stream);
+    if (rc != 0) return rc;
+    return bagel_rmsnorm_bf16(C, ldc, Xn, ldn, M, N, norm_weight, norm_weight, M, eps, stream);
+  }
+  GemmParams p;
+  p.A = (const bf16*)A; p.lda = lda;
+  p.W = (const bf16*)W; p.ldw = ldw;
+  p.C = (bf16*)C; p.ldc = ldc;
+  p.bias = nullptr;
+  p.R = (const bf16*)residual; p.ldr = ldr;
+  p.M = M; p.N = N; p.K = K; p.alpha = 1.0f;
+  p.diag = nullptr;
+  p.ksplit = 1;
+  p.slab = 0;
+  return launch_gemm_splitk(p, EPI_RESIDUAL, ksplit, (float*)workspace, (hipStream_t)stream, (const bf16*)norm_weight, (bf16*)Xn, ldn, eps);
 }
 
 extern "C" long bagel_gemm_workspace_bytes(int M, int N, int K, int epilogue) {

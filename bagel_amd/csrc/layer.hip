@@ -95,6 +95,8 @@ extern "C" int bagel_mot_layer_forward(const bagel_mot_dims* d, const bagel_mot_
   const int split = Mv ? Mv : M;
   // few understanding rows and nothing else: reduce + residual + the following RMSNorm share one launch
   const bool fuse_norm = Mv == 0 && Mt <= 16 && H <= 8192;   // und_linear() explains the exception
+  // the tile route of und_linear(): o_proj / down_proj share their reduce launch with the RMSNorm that follows
+  const bool tile_rows = Mv == 0 && Mt > 16 && H <= 8192;
   void* X_u = at(r->X, Mv, H);
   void* Xn_u = at(r->Xn, Mv, H);
 
@@ -149,6 +151,9 @@ extern "C" int bagel_mot_layer_forward(const bagel_mot_dims* d, const bagel_mot_
   if (fuse_norm) {
     TRY(bagel_skinny_gemm_residual_rmsnorm_bf16(r->O, qd, u.wo, qd, r->X, H, Mt, H, qd, r->X, H, u.ln_post, r->Xn, H, eps,
                                                 r->skinny_ws, r->skinny_ws_bytes, stream));
+  } else if (tile_rows) {
+    TRY(bagel_gemm_ws_residual_rmsnorm_bf16(r->O, qd, u.wo, qd, r->X, H, Mt, H, qd, r->X, H, u.ln_post, r->Xn, H, eps, r->skinny_ws,
+                                            r->skinny_ws_bytes, stream));
   } else {
     if (Mt) TRY(und_linear(at(r->O, Mv, qd), qd, u.wo, X_u, H, Mt, H, qd, nullptr, X_u, H, 1, r, stream));
     TRY(bagel_rmsnorm_bf16(r->X, H, r->Xn, H, M, H, ln_post_a, u.ln_post, split, eps, stream));
@@ -174,6 +179,11 @@ extern "C" int bagel_mot_layer_forward(const bagel_mot_dims* d, const bagel_mot_
   if (fuse_norm && next_norm_und) {
     TRY(bagel_skinny_gemm_residual_rmsnorm_bf16(r->Hm, I, u.wd, I, r->X, H, Mt, H, I, r->X, H, next_norm_und, r->Xn, H, eps,
                                                 r->skinny_ws, r->skinny_ws_bytes, stream));
+    return 0;
+  }
+  if (tile_rows && next_norm_und) {
+    TRY(bagel_gemm_ws_residual_rmsnorm_bf16(r->Hm, I, u.wd, I, r->X, H, Mt, H, I, r->X, H, next_norm_und, r->Xn, H, eps, r->skinny_ws,
+                                            r->skinny_ws_bytes, stream));
     return 0;
   }
   if (Mt) TRY(und_linear(at(r->Hm, Mv, I), I, u.wd, X_u, H, Mt, H, I, nullptr, X_u, H, 1, r, stream));

@@ -155,6 +155,16 @@ __global__ __launch_bounds__(RN_THREADS) void skinny_reduce_rmsnorm_kernel(const
   }
 }
 
+// The same reduce + residual + RMSNorm launch for partial tiles that another kernel left in [slices][M][N] order (the
+// split-K form of the tile GEMM, gemm.hip).  Returns false when the shape is outside the kernel's limits.
+bool bagel_launch_reduce_residual_rmsnorm(const float* part, int slices, int M, int N, const bf16* R, long ldr, bf16* C, long ldc,
+                                          const bf16* norm_w, bf16* Xn, long ldn, float eps, hipStream_t st) {
+  if (slices > 16 || N > RN_THREADS * RN_MAXC) return false;
+  hipLaunchKernelGGL(skinny_reduce_rmsnorm_kernel, dim3(M), dim3(RN_THREADS), 0, st, part, slices, M, N, R, ldr, C, ldc, norm_w, Xn,
+                     ldn, eps);
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // At most 4 token rows (a decode step of up to four samples): a GEMV-shaped kernel with no split-K and no partial
 // sums.  A wave owns NF weight rows over the WHOLE reduction; its 64 lanes split K in 16-byte pieces, so every load

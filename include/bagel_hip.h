@@ -47,6 +47,14 @@ int bagel_gemm_ws_bf16(const void* A, long lda, const void* W, long ldw, void* C
                        long workspace_bytes, void* stream);
 long bagel_gemm_workspace_bytes(int M, int N, int K, int epilogue);
 
+/* bagel_gemm_ws_bf16 with the residual epilogue, followed by the RMSNorm of the result: C = bf16(bf16(A . W^T) + R),
+ * Xn = norm_weight * bf16(C * rsqrt(mean(C^2) + eps)) - o_proj / down_proj of the understanding expert with the norm
+ * that follows them (qwen2_navit.py:605, 818-823, 833-836; modeling_qwen2.py:54-59).  Where the reduction is split
+ * (see above; N <= 8192) the launch that adds the partial tiles applies residual and norm too; C may be R. */
+int bagel_gemm_ws_residual_rmsnorm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N,
+                                        int K, const void* residual, long ldr, const void* norm_weight, void* Xn, long ldn,
+                                        float eps, void* workspace, long workspace_bytes, void* stream);
+
 /* epilogues of bagel_skinny_gemm_bf16 */
 #define BAGEL_SK_BIAS 0
 #define BAGEL_SK_RESIDUAL 1

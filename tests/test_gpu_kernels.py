@@ -145,6 +145,28 @@ def test_gemm_split_k_mid_rows(N, Kd, epi):
     assert k.gemm_workspace_bytes(1025, N, Kd, code) == 0 and k.gemm_workspace_bytes(16, N, Kd, code) == 0
 
 
+@pytest.mark.parametrize("M,N,Kd", [(40, 3584, 3584), (200, 3584, 18944), (700, 3584, 18944), (300, 1024, 256), (2000, 3584, 3584)])
+def test_gemm_residual_rmsnorm_matches_two_step(M, N, Kd):
+    """bagel_gemm_ws_residual_rmsnorm_bf16 against bagel_gemm_ws_bf16 + bagel_rmsnorm_bf16: the same C bit for bit (the
+    partial tiles are added in the same order), the normalised rows within an ulp (the row's sum of squares is added
+    in another order)."""
+    k = _K()
+    g = torch.Generator(device=DEV).manual_seed(31)
+    X = torch.randn((M, Kd), generator=g, device=DEV).to(BF16)
+    W = (torch.randn((N, Kd), generator=g, device=DEV) * 0.03).to(BF16)
+    R = torch.randn((M, N), generator=g, device=DEV).to(BF16)
+    nw = (torch.randn((N,), generator=g, device=DEV) * 0.1 + 1).to(BF16)
+    ws = torch.empty((max(k.gemm_workspace_bytes(M, N, Kd, k.EPI_RESIDUAL), 16),), dtype=torch.uint8, device=DEV)
+    C1, Xn1 = torch.empty((M, N), dtype=BF16, device=DEV), torch.empty((M, N), dtype=BF16, device=DEV)
+    k.gemm(X, W, C1, residual=R, epilogue=k.EPI_RESIDUAL, workspace=ws)
+    k.rmsnorm(C1, Xn1, nw, nw, M, 1e-6)
+    C2 = R.clone()                          # in place: the residual is the output
+    Xn2 = torch.full((M, N), float("nan"), dtype=BF16, device=DEV)
+    k.gemm_residual_rmsnorm(X, W, C2, C2, nw, Xn2, 1e-6, ws)
+    assert torch.equal(C1, C2)
+    _close(Xn2, Xn1, ulps=1.0, what="fused reduce + residual + RMSNorm")
+
+
 def test_gemm_random_shapes():
     """bagel_gemm_bf16 with the launcher's own tile choice over random row counts (ragged last tiles in both directions),
     widths, depths and every epilogue, against an fp32 product on the device."""

@@ -56,10 +56,11 @@ def _per_op_layer(K, w, X, Kw, Vt, cos, sin, row_cs, row_slot, tiles, n_tiles, S
     Xn, QKV, Q, O, Hm = buf(H), buf(qkv), buf(Hq * D), buf(Hq * D), buf(I)
     first = g if Mv else u
     split = Mv if Mv else M
-    fused = Mv == 0 and Mt <= 64
+    fused = Mv == 0 and Mt <= 16
+    tile = Mv == 0 and Mt > 16      # no generation rows: the tile kernels from 17 rows on, norms in the reduce launches
 
     def und(x, wt, out, **kw):
-        if x.shape[0] <= 64:
+        if x.shape[0] <= 64 and not tile:
             ep = {None: K.SK_BIAS, "residual": K.SK_RESIDUAL, "swiglu": K.SK_SWIGLU}[kw.pop("kind", None)]
             return K.skinny_gemm(x, wt, out, skw, epilogue=ep, **kw)
         ep = {None: K.EPI_BIAS, "residual": K.EPI_RESIDUAL, "swiglu": K.EPI_SWIGLU}[kw.pop("kind", None)]
@@ -77,6 +78,8 @@ def _per_op_layer(K, w, X, Kw, Vt, cos, sin, row_cs, row_slot, tiles, n_tiles, S
         K.gemm(O, g["wo"], X, residual=X, epilogue=K.EPI_RESIDUAL, M=Mv)
     if fused:
         K.skinny_gemm_residual_rmsnorm(O, u["wo"], X, X, u["ln_post"], Xn, eps, skw)
+    elif tile:
+        K.gemm_residual_rmsnorm(O, u["wo"], X, X, u["ln_post"], Xn, eps, skw)
     else:
         if Mt:
             und(O[Mv:], u["wo"], X[Mv:], residual=X[Mv:], kind="residual")
@@ -89,6 +92,8 @@ def _per_op_layer(K, w, X, Kw, Vt, cos, sin, row_cs, row_slot, tiles, n_tiles, S
         K.gemm(Hm, g["wd"], X, residual=X, epilogue=K.EPI_RESIDUAL, M=Mv)
     if fused and next_norms is not None:
         K.skinny_gemm_residual_rmsnorm(Hm, u["wd"], X, X, next_norms[1], Xn, eps, skw)
+    elif tile and next_norms is not None:
+        K.gemm_residual_rmsnorm(Hm, u["wd"], X, X, next_norms[1], Xn, eps, skw)
     else:
         if Mt:
             und(Hm[Mv:], u["wd"], X[Mv:], residual=X[Mv:], kind="residual")
@@ -97,7 +102,7 @@ def _per_op_layer(K, w, X, Kw, Vt, cos, sin, row_cs, row_slot, tiles, n_tiles, S
     return X, Xn
 
 
-@pytest.mark.parametrize("Mv,Mt,ctx", [(300, 6, 37), (0, 5, 90), (0, 150, 0), (256, 0, 10), (130, 70, 3)])
+@pytest.mark.parametrize("Mv,Mt,ctx", [(300, 6, 37), (0, 5, 90), (0, 150, 0), (0, 40, 20), (256, 0, 10), (130, 70, 3)])
 def test_layer_entry_matches_per_op_sequence(Mv, Mt, ctx):
     from bagel_amd import _lib as K
     H, I, Hq, Hkv, D = 256, 512, 2, 1, 128
