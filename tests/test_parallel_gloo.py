@@ -68,6 +68,17 @@ def test_two_ranks_single_image():
     _run(2, [64], 3)
 
 
+def test_four_and_eight_ranks_one_image_per_rank():
+    """The layouts `bench.py --gpus 4 / 8` runs: one image per rank, three branches; in the cond-only steps every
+    rank owns exactly one unit, and with a single image on four ranks one rank owns none."""
+    for world, nv in ((4, [8, 8, 8, 8]), (8, [8] * 8), (4, [12])):
+        res = _run(world, nv, 3)
+        owners = res[0][1]
+        counts = [owners.count(r) for r in range(world)]
+        assert max(counts) - min(counts) <= 1
+        assert all(r[1] == owners for r in res)
+
+
 def test_owner_balance():
     for world in (1, 2, 4, 8):
         for B in (1, 2, 8):
