@@ -1,9 +1,10 @@
 """Kernel-level parity: each C-ABI entry point against the CPU checker's restatement of the same op.
 
 bf16 outputs are compared after both sides round at the same points, so the tolerance is a couple of bf16
-ulps of the largest magnitude (2^-8 relative each) plus fp32 accumulation-order noise.
+ulps at the largest magnitude plus fp32 accumulation-order noise.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -26,9 +27,14 @@ def _rand(shape, std=1.0, seed=0, dtype=BF16):
     return (torch.randn(*shape, generator=g) * std).to(dtype)
 
 
-def _close(got, ref, ulps=2.0, what=""):
+def _close(got, ref, ulps=2.0, what="", mag=0.0):
+    """``mag``: largest magnitude of an intermediate that is rounded to bf16 on the way (a product rounded before a
+    residual is added can be larger than any output, and its ulp survives the add)."""
     got, ref = got.float().cpu(), ref.float().cpu()
-    tol = ulps * 2.0 ** -8 * float(ref.abs().max()) + 1e-6
+    # a bf16 ulp at the largest magnitude (spacing 2^(e-7) in [2^e, 2^(e+1))): two roundings that both fall on
+    # ties move a value by two of them (seen: 8.65625 -> 8.625 / 8.6875, then 11.03125 / 11.09375 -> 11.0 / 11.125)
+    scale = max(float(ref.abs().max()), float(mag), 1e-30)
+    tol = ulps * 2.0 ** (math.floor(math.log2(scale)) - 7) + 1e-6
     err = float((got - ref).abs().max())
     assert err <= tol, f"{what}: max-abs {err} > {tol}"
     # and almost all elements must agree to one ulp of their own magnitude
@@ -173,7 +179,7 @@ def test_gemm_random_shapes():
     import random
     k = _K()
     rnd = random.Random(5)
-    for case in range(30):
+    for case in range(int(os.environ.get("BAGEL_FUZZ_CASES", 30))):      # a longer soak: BAGEL_FUZZ_CASES=500
         M = rnd.choice([1, 7, 130, 255, 257, 1000, 4098, 6001, 12294])
         Kd = 64 * rnd.randint(1, 40)
         epi = rnd.choice(["bias", "residual", "swiglu", "bias_residual", "f32", "bias_gelu"])
@@ -186,6 +192,7 @@ def test_gemm_random_shapes():
         R = torch.randn((M, ncol), generator=g, device=DEV).to(BF16)
         acc = X.float() @ W.float().t()
         what = f"case {case}: M={M} N={N} K={Kd} {epi}"
+        mag = 0.0
         if epi == "f32":
             C = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
             k.gemm(X, W, C, epilogue=k.EPI_F32_SCALED, alpha=0.25)
@@ -198,9 +205,11 @@ def test_gemm_random_shapes():
         elif epi == "residual":
             k.gemm(X, W, C, residual=R, epilogue=k.EPI_RESIDUAL)
             ref = (acc.to(BF16).float() + R.float()).to(BF16)
+            mag = float(acc.abs().max())
         elif epi == "bias_residual":
             k.gemm(X, W, C, bias=b, residual=R, epilogue=k.EPI_BIAS_RESIDUAL)
             ref = ((acc + b.float()).to(BF16).float() + R.float()).to(BF16)
+            mag = float((acc + b.float()).abs().max())
         elif epi == "bias_gelu":
             k.gemm(X, W, C, bias=b, epilogue=k.EPI_BIAS_GELU)
             ref = torch.nn.functional.gelu((acc + b.float()).to(BF16).float(), approximate="tanh").to(BF16)
@@ -209,7 +218,7 @@ def test_gemm_random_shapes():
             a3 = acc.view(M, N // 32, 2, 16)
             gate, up = a3[:, :, 0].reshape(M, ncol).to(BF16).float(), a3[:, :, 1].reshape(M, ncol).to(BF16).float()
             ref = (torch.nn.functional.silu(gate).to(BF16).float() * up).to(BF16)
-        _close(C, ref, ulps=4.0 if epi in ("swiglu", "bias_gelu") else 2.0, what=what)
+        _close(C, ref, ulps=4.0 if epi in ("swiglu", "bias_gelu") else 2.0, what=what, mag=mag)
 
 
 def test_linear_entry_points_random_shapes(monkeypatch):
@@ -442,7 +451,7 @@ def test_varlen_attention_random_cases():
     key tile), head counts, head widths, masks and kernel forms against the checker's attention."""
     import random
     rnd = random.Random(11)
-    for case in range(24):
+    for case in range(int(os.environ.get("BAGEL_FUZZ_CASES", 24))):
         n = rnd.randint(1, 4)
         q_lens = [rnd.choice([1, 2, 31, 64, 65, 127, 128, 129, 200, 300]) for _ in range(n)]
         ctx_lens = [rnd.choice([0, 1, 7, 63, 64, 65, 130, 500]) for _ in range(n)]

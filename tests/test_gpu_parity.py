@@ -83,6 +83,46 @@ def test_matches_cpu_checker_on_fresh_inputs():
             assert cos >= 0.999 and ma <= 4e-2, (key, ma, cos)
 
 
+def test_random_scenarios_match_cpu_checker():
+    """Random batch sizes, image sizes, context lengths per CFG branch (empty contexts included), depths, CFG scales,
+    intervals and renorm types through the HIP path and through oracle/ on the same seeded inputs, teacher-forced.
+    BAGEL_FUZZ_SCENARIOS=n runs n of them (default 4)."""
+    import os
+    import random
+    from bagel_amd.config import tiny_dims
+    from tests.scenarios import Scenario
+    rnd = random.Random(2024)
+    n_cases = int(os.environ.get("BAGEL_FUZZ_SCENARIOS", 4))
+    for case in range(n_cases):
+        B = rnd.randint(1, 3)
+        images = [(16 * rnd.randint(2, 14), 16 * rnd.randint(2, 14)) for _ in range(B)]
+        lens = lambda: [rnd.choice([1, 2, 5, 31, 62, 63, 64, 65, 130, 200]) for _ in range(B)]   # noqa: E731
+        cond = lens()
+        text = rnd.choice([None, lens()])
+        img = rnd.choice([None, cond, lens()])
+        sc = Scenario(f"random{case}", tiny_dims(rnd.randint(1, 3)), images, cond, text, img, num_timesteps=5,
+                      timestep_shift=rnd.choice([1.0, 3.0]), cfg_text_scale=rnd.choice([1.0, 2.5, 4.0]),
+                      cfg_img_scale=rnd.choice([1.0, 1.5, 2.0]), cfg_interval=rnd.choice([(0.0, 1.0), (0.4, 1.0), (0.3, 0.8)]),
+                      cfg_renorm_min=rnd.choice([0.0, 0.3]), cfg_renorm_type=rnd.choice(["global", "channel", "text_channel"]),
+                      weight_seed=case % 3, noise_seed=500 + case)
+        what = f"case {case}: {images} cond {cond} text {text} img {img} L={sc.dims.num_layers} scales " \
+               f"{sc.cfg_text_scale}/{sc.cfg_img_scale} {sc.cfg_interval} {sc.cfg_renorm_type} min {sc.cfg_renorm_min}"
+        run = OracleRun(sc)
+        otrace, trace = [], []
+        run.generate(trace=otrace, max_steps=3)
+        run_scenario_on_gpu(sc, run, trace=trace, max_steps=3, teacher_x=[r["x_t"] for r in otrace])
+        assert len(trace) == len(otrace) == 3, what
+        for i, (a, b) in enumerate(zip(trace, otrace)):
+            for key in ("v_cond", "v_text", "v_img", "v_t"):
+                if b.get(key) is None or key not in a:
+                    continue
+                ma, cos = metrics(a[key], b[key])
+                # a combined velocity amplifies the branches' rounding differences by the CFG scales
+                amp = 1.0 if key != "v_t" else max(sc.cfg_text_scale, 1.0) * max(sc.cfg_img_scale, 1.0) * 2.0
+                assert cos >= (0.999 if key != "v_t" else 0.995) and ma <= 4e-2 * amp, (what, i, key, ma, cos)
+    print(f"{n_cases} random scenarios agree with the CPU checker")
+
+
 def test_api_errors():
     sc = SCENARIOS["tiny_t2i"]
     run = OracleRun(sc)
