@@ -68,6 +68,49 @@ def test_generate_text_teacher_forced_logits(name):
     assert torch.equal(logits.argmax(-1)[clear], ref.argmax(-1)[clear])
 
 
+def test_random_decode_batches_match_cpu_checker():
+    """Random sample counts (1 ... 24: the GEMV, weight-streaming and tile forms of a decode step), prompt lengths and
+    depths: the CPU checker decodes greedily, the HIP path is fed the checker's tokens and must give its logits.
+    BAGEL_FUZZ_DECODE=n runs n cases (default 5)."""
+    import os
+    import random
+    from bagel_amd.config import tiny_dims
+    from bagel_amd.weights import make_llm_state_dict
+    from tests.helpers import O, oracle_context
+    from tests.scenarios import TextCase
+    rnd = random.Random(77)
+    n_cases = int(os.environ.get("BAGEL_FUZZ_DECODE", 5))
+    for case in range(n_cases):
+        n = rnd.choice([1, 2, 3, 4, 5, 7, 12, 16, 17, 24])
+        tc = TextCase(f"random{case}", tiny_dims(rnd.randint(1, 3)), [rnd.choice([1, 3, 30, 62, 63, 64, 65, 140]) for _ in range(n)],
+                      rnd.randint(3, 9), weight_seed=case % 4)
+        what = f"case {case}: prompts {tc.prompt} L={tc.dims.num_layers} max_length {tc.max_length}"
+        model = _model(tc)
+        sd = make_llm_state_dict(tc.dims, seed=tc.weight_seed, include_lm_head=True)
+        with torch.no_grad():
+            opast, okv, oropes = oracle_context(sd, tc.dims, tc.prompts(), n)
+            ogi = O.prepare_start_tokens(okv, oropes, NEW_TOKEN_IDS)
+            otrace = []
+            otokens = O.generate_text(sd, tc.dims, opast, max_length=tc.max_length, logits_trace=otrace, **ogi)
+        past, kvlens, ropes = _context(model, tc)
+        gi = model.prepare_start_tokens(kvlens, ropes, NEW_TOKEN_IDS)
+        ref_tokens = otokens.to("cuda:0")
+        step = [0]
+
+        def forced(logits):
+            step[0] += 1
+            return ref_tokens[min(step[0], ref_tokens.shape[0] - 1)]
+
+        trace = []
+        model.engine.decode_tokens(gi["packed_start_tokens"].tolist(), gi["packed_query_position_ids"].tolist(), kvlens,
+                                   *_split_ctx(model, past, kvlens), tc.max_length, sample_fn=forced, logits_trace=trace)
+        logits, ref = torch.stack(trace).float().cpu(), torch.stack(otrace).float()
+        assert logits.shape == ref.shape, what
+        ma, cos = metrics(logits, ref)
+        assert ma <= _logit_bound(ref) and cos >= 0.9999, (what, ma, cos)
+    print(f"{n_cases} random decode batches agree with the CPU checker")
+
+
 def _split_ctx(model, past, kvlens):
     L = model.dims.num_layers
     ks, vs, c = [], [], 0
