@@ -44,9 +44,44 @@ def _snap_check(tag, past, g, L):
 
 @pytest.mark.parametrize("name", list(IMAGE_CTX_CASES))
 def test_image_context_matches_reference(name):
+    _check_case(IMAGE_CTX_CASES[name], load_golden(name))
+
+
+def test_random_image_contexts_match_cpu_checker():
+    """Random batches of prompts, VAE-encoded and ViT-encoded images (sizes, counts and order of stages vary; mixed
+    resolutions inside a batch) through the HIP path and through oracle/ on the same seeded inputs: encoder moments,
+    tower output and the context keys / values after every stage.  BAGEL_FUZZ_IMAGE_CTX=n runs n cases (default 3)."""
+    import os
+    import random
+    from bagel_amd.config import tiny_dims
+    from tests.scenarios import ImageCtxCase
+    from tests.test_oracle_image_ctx import run_oracle_case
+    rnd = random.Random(31)
+    n_cases = int(os.environ.get("BAGEL_FUZZ_IMAGE_CTX", 3))
+    for case in range(n_cases):
+        B = rnd.randint(1, 3)
+        first = rnd.choice([None, [rnd.randint(1, 40) for _ in range(B)]])
+        vae_images = rnd.choice([None, [(16 * rnd.randint(2, 8), 16 * rnd.randint(2, 8)) for _ in range(B)]])
+        vit_images = rnd.choice([None, [(14 * rnd.randint(1, 8), 14 * rnd.randint(1, 8)) for _ in range(B)]])
+        if vae_images is None and vit_images is None:
+            vit_images = [(14 * rnd.randint(1, 8), 14 * rnd.randint(1, 8)) for _ in range(B)]
+        ic = ImageCtxCase(f"random{case}", tiny_dims(rnd.randint(1, 3), vit=True), first, vae_images, vit_images,
+                          weight_seed=case % 3, image_seed=100 + case)
+        g = {}
+        if vae_images is not None:   # the posterior draw, one latent grid per padded image
+            hm, wm = max(h for h, _ in vae_images), max(w for _, w in vae_images)
+            g["vae.noise"] = torch.randn((B, ic.dims.vae.z_channels, hm // 8, wm // 8), generator=torch.Generator().manual_seed(case))
+        _, _, out = run_oracle_case(ic, g)
+        g.update({k: v for k, v in out.items() if isinstance(v, torch.Tensor)})
+        try:
+            _check_case(ic, g)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: prompts {first} vae {vae_images} vit {vit_images} L={ic.dims.num_layers}: {e}")
+    print(f"{n_cases} random image contexts agree with the CPU checker")
+
+
+def _check_case(ic, g):
     from bagel_amd.modeling import NaiveCache
-    ic = IMAGE_CTX_CASES[name]
-    g = load_golden(name)
     model, vae = _build(ic)
     ident = lambda x: x  # noqa: E731
     n, L = ic.batch, ic.dims.num_layers
