@@ -108,6 +108,30 @@ def test_decode_matches_reference(name):
     assert float((u8.int() - r8.int()).abs().float().mean()) < 1.0
 
 
+def test_decode_random_latent_sizes_match_cpu_checker():
+    """Latent grids of random, mostly non-square sizes (rows x columns not a multiple of the GEMM's K step included)
+    against the CPU checker's fp32 decode of the same latent.  BAGEL_FUZZ_VAE=n runs n sizes (default 3)."""
+    import os
+    import random
+    from bagel_amd.modeling import AutoEncoder
+    from oracle import bagel_oracle as O
+    vd = VAEDims()
+    sd = make_vae_decoder_state_dict(vd, seed=0)
+    ae = AutoEncoder(vd, sd, DEV)
+    rnd = random.Random(3)
+    n_cases = int(os.environ.get("BAGEL_FUZZ_VAE", 3))
+    for case in range(n_cases):
+        h, w = 2 * rnd.randint(1, 10), 2 * rnd.randint(1, 10)     # BAGEL latents are 2 x 2-patchified: even sides
+        z = _rand((1, vd.z_channels, h, w), 1.0, 300 + case)
+        img = ae.decode(z).float().cpu()
+        with torch.no_grad():
+            ref = O.vae_decode(sd, vd, z, bf16=False)
+        assert img.shape == ref.shape and torch.isfinite(img).all(), (case, h, w)
+        p = psnr(img, ref)
+        assert p >= 40.0, (case, h, w, p)
+    print(f"{n_cases} random latent sizes decode within 40 dB of the CPU checker's fp32 decode")
+
+
 def test_mid_block_attention_chunking_is_exact():
     """The mid-block attention computes its fp32 scores in query-row chunks; the chunk size must not change a bit.
     64 x 64 latent (4096 tokens): one chunk by default, four chunks of 1024 rows when forced."""
