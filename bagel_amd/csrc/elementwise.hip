@@ -150,7 +150,9 @@ __global__ __launch_bounds__(256) void v_scatter_transposed_kernel(const bf16* _
   const long slot = row_slot[row];
   const bf16* src = qkv + (long)row * ld + v_col0;
   const int nchunk = Hkv * D / 8;
-  for (int c = part; c < nchunk; c += 4) {
+  // gridDim.y workgroups share a 64-row block's chunks: 64 rows per workgroup alone are too few workgroups to fill the
+  // chip at a few thousand rows (192 at 12288 rows)
+  for (int c = part + 4 * blockIdx.y; c < nchunk; c += 4 * gridDim.y) {
     const bf16x8 v = *(const bf16x8*)(src + 8 * c);
     bf16* dst = Vt + (long)(8 * c) * S + slot;  // (kvh*D + d) * S with kvh*D + d == 8c + e
 #pragma unroll
@@ -174,16 +176,19 @@ extern "C" int bagel_qk_norm_rope_kv_bf16(const void* qkv, long ld, int M, int H
   const int lph = head_dim / 8;
   const long threads = (long)M * (Hq + Hkv) * lph;
   const dim3 grid((threads + 255) / 256), block(256);
+  // value scatter: up to 8 workgroups per 64-row block while that still leaves each wave a chunk (Hkv * D / 8 chunks, 4 waves)
+  int v_split = 1;
+  while (v_split < 8 && (long)((M + 63) / 64) * v_split < 4L * bagel_cu_count() && Hkv * head_dim / 8 >= 8 * v_split) v_split *= 2;
 #define ARGS (const bf16*)qkv, ld, M, Hq, Hkv, (const bf16*)q_norm_first, (const bf16*)q_norm_second,                \
              (const bf16*)k_norm_first, (const bf16*)k_norm_second, split_row, (const bf16*)cos_table,               \
              (const bf16*)sin_table, (const int*)row_cs, (const int*)row_slot, (bf16*)Q, (bf16*)K_ws, S, eps, und_rounding
   if (head_dim == 128) {
     hipLaunchKernelGGL(qk_norm_rope_kernel<128>, grid, block, 0, st, ARGS);
-    hipLaunchKernelGGL(v_scatter_transposed_kernel<128>, dim3((M + 63) / 64), block, 0, st, (const bf16*)qkv, ld, M,
+    hipLaunchKernelGGL(v_scatter_transposed_kernel<128>, dim3((M + 63) / 64, v_split), block, 0, st, (const bf16*)qkv, ld, M,
                        (Hq + Hkv) * head_dim, Hkv, (const int*)row_slot, (bf16*)Vt_ws, S);
   } else {
     hipLaunchKernelGGL(qk_norm_rope_kernel<64>, grid, block, 0, st, ARGS);
-    hipLaunchKernelGGL(v_scatter_transposed_kernel<64>, dim3((M + 63) / 64), block, 0, st, (const bf16*)qkv, ld, M,
+    hipLaunchKernelGGL(v_scatter_transposed_kernel<64>, dim3((M + 63) / 64, v_split), block, 0, st, (const bf16*)qkv, ld, M,
                        (Hq + Hkv) * head_dim, Hkv, (const int*)row_slot, (bf16*)Vt_ws, S);
   }
 #undef ARGS
