@@ -120,21 +120,37 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16* __restric
                                                            bf16* __restrict__ Kws, long S, float eps,
                                                            int und_rounding) {
   constexpr int LPH = D / 8;
+  // Two token rows per thread (four measured slower), every load of both issued before the first result is needed: with one 16-byte load in
+  // flight per lane the kernel is bound by (resident waves x bytes per wave) / memory latency, not by the memory system.
+  constexpr int U = 2;
   const int NH = Hq + Hkv;
   const long item = ((long)blockIdx.x * 256 + threadIdx.x) / LPH;
-  if (item >= (long)M * NH) return;  // M*NH*LPH is a multiple of 64 only if ...; partial waves shuffle among live lanes only
+  const long pairs = (M + U - 1) / U;
+  if (item >= pairs * NH) return;  // partial waves shuffle among live lanes only (a head's lanes leave together)
   const int j = threadIdx.x % LPH;
-  const int row = item / NH, head = item % NH;
+  const int row0 = (int)(item / NH) * U, head = item % NH;
   const bool is_q = head < Hq;
-  const bf16* src = qkv + (long)row * ld + (long)head * D + 8 * j;  // q heads then k heads are contiguous
-  const bf16x8 v = *(const bf16x8*)src;
-  const bf16* w = is_q ? (row < split ? qw_first : qw_second) : (row < split ? kw_first : kw_second);
-  const long cs = (long)row_cs[row] * D;
-  const bf16x8 o = qk_norm_rope_lane<D>(v, j, w, cos_t + cs, sin_t + cs, eps, und_rounding);
-  if (is_q)
-    *(bf16x8*)(Q + ((long)row * Hq + head) * D + 8 * j) = o;
-  else
-    *(bf16x8*)(Kws + ((long)(head - Hq) * S + row_slot[row]) * D + 8 * j) = o;
+  bf16x8 v[U];
+  long cs[U];
+  int slot[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int row = min(row0 + u, M - 1);
+    v[u] = *(const bf16x8*)(qkv + (long)row * ld + (long)head * D + 8 * j);  // q heads then k heads are contiguous
+    cs[u] = (long)row_cs[row] * D;
+    slot[u] = row_slot[row];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int row = row0 + u;
+    if (row >= M) break;
+    const bf16* w = is_q ? (row < split ? qw_first : qw_second) : (row < split ? kw_first : kw_second);
+    const bf16x8 o = qk_norm_rope_lane<D>(v[u], j, w, cos_t + cs[u], sin_t + cs[u], eps, und_rounding);
+    if (is_q)
+      *(bf16x8*)(Q + ((long)row * Hq + head) * D + 8 * j) = o;
+    else
+      *(bf16x8*)(Kws + ((long)(head - Hq) * S + slot[u]) * D + 8 * j) = o;
+  }
 }
 
 // V rows of the fused qkv projection -> transposed value workspace Vt[kvh][d][slot] (2-byte stores,
@@ -174,7 +190,7 @@ extern "C" int bagel_qk_norm_rope_kv_bf16(const void* qkv, long ld, int M, int H
   BAGEL_CHECK(split_row >= M || (q_norm_second && k_norm_second), "bagel_qk_norm_rope_kv_bf16: rows past split_row need second weights");
   hipStream_t st = (hipStream_t)stream;
   const int lph = head_dim / 8;
-  const long threads = (long)M * (Hq + Hkv) * lph;
+  const long threads = (long)((M + 1) / 2) * (Hq + Hkv) * lph;   // two token rows per thread
   const dim3 grid((threads + 255) / 256), block(256);
   // value scatter: up to 8 workgroups per 64-row block while that still leaves each wave a chunk (Hkv * D / 8 chunks, 4 waves)
   int v_split = 1;
