@@ -272,6 +272,18 @@ __global__ __launch_bounds__(1024) void decode_attention_kernel(DecParams p) {
   // device-scope accesses: write-through stores, then the ticket, then device-scope loads in the last workgroup.
   // A release / acquire fence pair instead costs an L2 write-back per workgroup, and those queue up per XCD: with 18
   // chunks per kv head (9 k keys) the launch took 30 us longer than this form.
+  // CONTRACT (hardware, not the HIP memory model: relaxed agent-scope atomics and a workgroup fence give no
+  // happens-before edge between workgroups on paper).  It holds because of how gfx950 executes exactly these forms:
+  //   * every store to `part` is an agent-scope atomic store = `global_store_dword ... sc1` (write-through: the bytes
+  //     leave this XCD's L2 without a buffer_wbl2);
+  //   * every storing wave drains them with `s_waitcnt vmcnt(0)` BEFORE the workgroup barrier, and only then does
+  //     one lane add to the ticket (agent-scope atomic, executed at the memory side);
+  //   * the last-arriving workgroup learns it from the value its own add returned, its other waves start loading
+  //     only behind the barrier that follows, and every load of `part` is an agent-scope atomic load =
+  //     `global_load_dword ... sc1` (bypasses this CU's L1, which other CUs' stores never refresh).
+  // A plain (non-atomic) access to `part`, a `flat_` form of these accesses, or a target that lowers agent-scope
+  // relaxed atomics without sc1 breaks it silently; test_decode_attention_matches_three_launch_path (34 splits,
+  // partials crossing XCDs) is the guard, and the disassembly must keep showing `sc1` on these instructions.
   float* part = p.part + (((long)m * p.Hkv + g) * MAX_SPLITS) * REP * PW;
   if (mine_out) {
     float* mine = part + ((long)c * REP + oh) * PW;

@@ -231,7 +231,6 @@ static int gemm_entry(const void* A, long lda, const void* W, long ldw, void* C,
   BAGEL_CHECK(N % 4 == 0, "bagel_gemm_bf16: N=%d must be a multiple of 4", N);
   BAGEL_CHECK(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, "bagel_gemm_bf16: bad leading dims");
   BAGEL_CHECK(lda < (1L << 21) && ldw < (1L << 21), "bagel_gemm_bf16: leading dims beyond the 31-bit tile offsets");
-  BAGEL_CHECK(lda < (1L << 21) && ldw < (1L << 21), "bagel_gemm_bf16: leading dims beyond the 31-bit tile offsets");
   BAGEL_CHECK(ldc % 4 == 0, "bagel_gemm_bf16: ldc must be a multiple of 4");
   BAGEL_CHECK(((uintptr_t)A | (uintptr_t)W) % 16 == 0 && (uintptr_t)C % 8 == 0, "bagel_gemm_bf16: misaligned operand");
   if (epilogue == EPI_RESIDUAL || epilogue == EPI_BIAS_RESIDUAL)
@@ -280,7 +279,7 @@ extern "C" int bagel_gemm_bf16(const void* A, long lda, const void* W, long ldw,
   return gemm_entry(A, lda, W, ldw, C, ldc, M, N, K, bias, residual, ldr, epilogue, alpha, nullptr, 0, stream);
 }
 
-// The same product with a workspace: 65 ... 512 rows of a projection with few column tiles take the split-K form when
+// The same product with a workspace: 17 ... 1024 rows of a projection with few column tiles take the split-K form when
 // the workspace holds bagel_gemm_workspace_bytes(M, N, K, epilogue); anything else runs as bagel_gemm_bf16 does.
 extern "C" int bagel_gemm_ws_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N,
                                   int K, const void* bias, const void* residual, long ldr, int epilogue,

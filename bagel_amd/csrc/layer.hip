@@ -35,10 +35,22 @@ int und_linear(const void* in, long ld_in, const void* W, void* out, long ld_out
   // rows takes the tile kernels, which share every token-row fragment through LDS: 186 against 282 us per layer at 64
   // rows; its bits then depend on the row class (17 ... 512, 513 ... 1024, more), not on the row count inside it.
   const bool decode_tiles = r->rows_gen == 0 && n > 16;
-  if (n <= 64 && !decode_tiles) {
-    const int ep = kind == 0 ? BAGEL_SK_BIAS : kind == 1 ? BAGEL_SK_RESIDUAL : BAGEL_SK_SWIGLU;
-    return bagel_skinny_gemm_bf16(in, ld_in, W, K, out, ld_out, n, N, K, bias, residual, ldr, ep, r->skinny_ws,
+  const int sk_ep = kind == 0 ? BAGEL_SK_BIAS : kind == 1 ? BAGEL_SK_RESIDUAL : BAGEL_SK_SWIGLU;
+  if (n <= 64 && !decode_tiles)
+    return bagel_skinny_gemm_bf16(in, ld_in, W, K, out, ld_out, n, N, K, bias, residual, ldr, sk_ep, r->skinny_ws,
                                   r->skinny_ws_bytes, stream);
+  if (r->rows_gen > 0) {
+    // Text rows beside generation rows (two per (sample, CFG branch) unit, so more than 32 units in one forward):
+    // a unit's bits must not depend on how many other units share the launch - the same units split over ranks, or
+    // run alone, stay at 64 rows or fewer - so the rows keep the weight-streaming kernel, 64 at a time.
+    for (int r0 = 0; r0 < n; r0 += 64) {
+      const int m = n - r0 < 64 ? n - r0 : 64;
+      if (int rc = bagel_skinny_gemm_bf16(at(in, r0, ld_in), ld_in, W, K, at(out, r0, ld_out), ld_out, m, N, K, bias,
+                                          residual ? at(residual, r0, ldr) : nullptr, ldr, sk_ep, r->skinny_ws,
+                                          r->skinny_ws_bytes, stream))
+        return rc;
+    }
+    return 0;
   }
   const int ep = kind == 0 ? BAGEL_EPI_BIAS : kind == 1 ? BAGEL_EPI_RESIDUAL : BAGEL_EPI_SWIGLU;
   // 17 ... 1024 rows (a text prompt's prefill, a large decode batch) split the reduction of the narrow projections over the chip
@@ -59,7 +71,7 @@ extern "C" int bagel_profile_collect(double* ms, double* flops, int cap) {
   int n = 0;
   for (auto& t : g_prof) {
     float m = 0.f;
-    if (hipEventSynchronize(t.stop) == hipSuccess && hipEventElapsedTime(&m, t.start, t.stop) == hipSuccess && n < cap) {
+    if (t.flops > 0 && hipEventSynchronize(t.stop) == hipSuccess && hipEventElapsedTime(&m, t.start, t.stop) == hipSuccess && n < cap) {
       ms[n] = m;
       flops[n] = t.flops;
       ++n;
@@ -99,6 +111,9 @@ extern "C" int bagel_mot_layer_forward(const bagel_mot_dims* d, const bagel_mot_
   const bool tile_rows = Mv == 0 && Mt > 16 && H <= 8192;
   void* X_u = at(r->X, Mv, H);
   void* Xn_u = at(r->Xn, Mv, H);
+  // last layer of a generation forward: the text rows' keys / values are still needed (the latent rows attend to
+  // them), what the layer would add to their hidden state is not
+  const bool drop_und_out = (flags & BAGEL_LAYER_UND_OUT_UNUSED) && Mv > 0;
 
   if (flags & BAGEL_LAYER_NORM_IN_GEMM) {
     // understanding rows only, a handful of them (a decode step): both RMSNorms are applied inside the
@@ -155,27 +170,36 @@ extern "C" int bagel_mot_layer_forward(const bagel_mot_dims* d, const bagel_mot_
     TRY(bagel_gemm_ws_residual_rmsnorm_bf16(r->O, qd, u.wo, qd, r->X, H, Mt, H, qd, r->X, H, u.ln_post, r->Xn, H, eps, r->skinny_ws,
                                             r->skinny_ws_bytes, stream));
   } else {
-    if (Mt) TRY(und_linear(at(r->O, Mv, qd), qd, u.wo, X_u, H, Mt, H, qd, nullptr, X_u, H, 1, r, stream));
-    TRY(bagel_rmsnorm_bf16(r->X, H, r->Xn, H, M, H, ln_post_a, u.ln_post, split, eps, stream));
+    if (Mt && !drop_und_out) TRY(und_linear(at(r->O, Mv, qd), qd, u.wo, X_u, H, Mt, H, qd, nullptr, X_u, H, 1, r, stream));
+    TRY(bagel_rmsnorm_bf16(r->X, H, r->Xn, H, drop_und_out ? Mv : M, H, ln_post_a, u.ln_post, split, eps, stream));
   }
   if (Mv) {
     TimedLaunch t{};
     bool timed = false;
     {
       std::lock_guard<std::mutex> lock(g_prof_mu);
-      timed = g_prof_on && hipEventCreate(&t.start) == hipSuccess && hipEventCreate(&t.stop) == hipSuccess;
+      if (g_prof_on && hipEventCreate(&t.start) == hipSuccess) {
+        timed = hipEventCreate(&t.stop) == hipSuccess;
+        if (!timed) (void)hipEventDestroy(t.start);
+      }
     }
     if (timed) (void)hipEventRecord(t.start, (hipStream_t)stream);
-    TRY(bagel_gemm_bf16(r->Xn, H, g.wgu, H, r->Hm, I, Mv, 2 * I, H, nullptr, nullptr, 0, BAGEL_EPI_SWIGLU, 1.0f, stream));
+    const int rc_gu = bagel_gemm_bf16(r->Xn, H, g.wgu, H, r->Hm, I, Mv, 2 * I, H, nullptr, nullptr, 0, BAGEL_EPI_SWIGLU, 1.0f, stream);
     if (timed) {
+      // recorded and handed to the collector even when the launch failed, so the pair is always destroyed there
       (void)hipEventRecord(t.stop, (hipStream_t)stream);
-      t.flops = 2.0 * Mv * 2.0 * I * H;
+      t.flops = rc_gu ? 0.0 : 2.0 * Mv * 2.0 * I * H;
       std::lock_guard<std::mutex> lock(g_prof_mu);
       g_prof.push_back(t);
     }
+    if (rc_gu) return rc_gu;
   }
-  if (Mt) TRY(und_linear(Xn_u, H, u.wgu, at(r->Hm, Mv, I), I, Mt, 2 * I, H, nullptr, nullptr, 0, 2, r, stream));
+  if (Mt && !drop_und_out) TRY(und_linear(Xn_u, H, u.wgu, at(r->Hm, Mv, I), I, Mt, 2 * I, H, nullptr, nullptr, 0, 2, r, stream));
   if (Mv) TRY(bagel_gemm_bf16(r->Hm, I, g.wd, I, r->X, H, Mv, H, I, nullptr, r->X, H, BAGEL_EPI_RESIDUAL, 1.0f, stream));
+  if (drop_und_out) {
+    if (next_norm_gen) TRY(bagel_rmsnorm_bf16(r->X, H, r->Xn, H, Mv, H, next_norm_gen, next_norm_gen, Mv, eps, stream));
+    return 0;
+  }
   if (fuse_norm && next_norm_und) {
     TRY(bagel_skinny_gemm_residual_rmsnorm_bf16(r->Hm, I, u.wd, I, r->X, H, Mt, H, I, r->X, H, next_norm_und, r->Xn, H, eps,
                                                 r->skinny_ws, r->skinny_ws_bytes, stream));
@@ -215,6 +239,8 @@ extern "C" int bagel_mot_forward(const bagel_mot_dims* d, const bagel_mot_layer*
     const bool last = l + 1 == n_layers;
     int flags = l > 0 ? BAGEL_LAYER_XN_READY : 0;     // every layer leaves the next one's input norm in Xn
     if (last && kv_only_last) flags |= BAGEL_LAYER_KV_ONLY;
+    // the caller reads the generation rows only (the velocity head, bagel.py:1425-1426)
+    if (last && !kv_only_last && Mv > 0 && final_norm_rows > 0 && final_norm_rows <= Mv) flags |= BAGEL_LAYER_UND_OUT_UNUSED;
     // the norm that follows layer l: the next layer's input norm, or the model's final norm when it covers all rows
     const bool final_here = last && !kv_only_last && final_norm_rows <= 0;
     const void* ng = last ? (final_here ? final_norm_gen : nullptr) : layers[l + 1].gen.ln_in;

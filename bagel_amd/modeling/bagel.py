@@ -445,9 +445,8 @@ class Bagel:
 
         # split the units over the ranks (one process per GPU); world == 1 keeps everything local
         rank, world = world_info(group)
-        n_br = 1 + int(use_text) + int(use_img and not img_is_cond)
-        ex_full = plan_exchange([u.sample for u in units], [u.branch for u in units], sample_nv, n_br, rank, world)
-        ex_cond = plan_exchange([u.sample for u in units[:n_cond]], [0] * n_cond, sample_nv, n_br, rank, world)
+        ex_full = plan_exchange([u.sample for u in units], [u.branch for u in units], sample_nv, rank, world)
+        ex_cond = plan_exchange([u.sample for u in units[:n_cond]], [0] * n_cond, sample_nv, rank, world)
         local_full = [units[i] for i in ex_full.local_units]
         local_cond = [units[i] for i in ex_cond.local_units]   # a prefix of local_full: same key slots
         plan_full = eng.build_plan(local_full, sample_nv, sample_row0) if local_full else None

@@ -26,10 +26,13 @@ def world_info(group=None) -> Tuple[int, int]:
     return 0, 1
 
 
-def unit_owner(sample: int, branch: int, n_branches: int, world: int) -> int:
-    """Round-robin over the sample-major unit index.  The cond unit of sample b lands on rank
-    (n_branches*b) % world in CFG steps and in cond-only steps alike, so its KV context is staged once."""
-    return (n_branches * sample + branch) % world
+def unit_owner(sample: int, branch: int, n_samples: int, world: int) -> int:
+    """Round-robin over the BRANCH-major unit index (all cond units, then all text-free units, then all image-free
+    units).  The cond unit of sample b lands on rank b % world in CFG steps and in cond-only steps alike, so its KV
+    context is staged once, and both kinds of step are balanced to within one unit for any number of branches: the
+    cond-only steps spread over every rank (a sample-major deal puts all cond units of a two-branch request - text
+    CFG only, eval/gen/gen_images_mp.py:74-80 - on the even ranks of an even world)."""
+    return (branch * n_samples + sample) % world
 
 
 @dataclass
@@ -39,6 +42,7 @@ class StepExchange:
     rows_max: int                 # padded per-rank row count of the gather buffer
     index: torch.Tensor           # [n_branches_active * Nv] row of the gathered buffer for every global row
     world: int
+    identity: bool = False        # the gathered buffer already is the global row order (index = 0, 1, 2, ...)
     send: Optional[torch.Tensor] = None   # [rows_max, width] and [world * rows_max, width]: allocated at the first
     recv: Optional[torch.Tensor] = None   # step of an image and reused by every later step of this kind
 
@@ -47,10 +51,10 @@ class StepExchange:
         return self.world > 1
 
 
-def plan_exchange(unit_sample: Sequence[int], unit_branch: Sequence[int], sample_nv: Sequence[int], n_branches: int,
-                  rank: int, world: int) -> StepExchange:
+def plan_exchange(unit_sample: Sequence[int], unit_branch: Sequence[int], sample_nv: Sequence[int], rank: int,
+                  world: int) -> StepExchange:
     """``unit_*`` describe the global branch-major unit list of this kind of step."""
-    owners = [unit_owner(s, b, n_branches, world) for s, b in zip(unit_sample, unit_branch)]
+    owners = [unit_owner(s, b, len(sample_nv), world) for s, b in zip(unit_sample, unit_branch)]
     rows = [0] * world
     offset = []
     for s, o in zip(unit_sample, owners):
@@ -63,7 +67,8 @@ def plan_exchange(unit_sample: Sequence[int], unit_branch: Sequence[int], sample
         idx.append(torch.arange(base, base + sample_nv[s], dtype=torch.long))
     index = torch.cat(idx) if idx else torch.empty(0, dtype=torch.long)
     local = [i for i, o in enumerate(owners) if o == rank]
-    return StepExchange(local, rows_max, index, world)
+    identity = bool(torch.equal(index, torch.arange(index.numel(), dtype=torch.long)))
+    return StepExchange(local, rows_max, index, world, identity)
 
 
 def exchange_velocities(local_v: Optional[torch.Tensor], ex: StepExchange, width: int, device, dtype,
@@ -87,4 +92,6 @@ def exchange_velocities(local_v: Optional[torch.Tensor], ex: StepExchange, width
         # ("nccl") orders the gather behind the stream's work itself.
         torch.cuda.current_stream().synchronize()
     dist.all_gather_into_tensor(recv, send, group=group)
+    if ex.identity:            # one equal-sized unit per rank, in rank order: nothing to re-order
+        return recv[:ex.index.numel()]
     return recv.index_select(0, ex.index)

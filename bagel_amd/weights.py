@@ -74,7 +74,7 @@ def llm_layer_names(i: int) -> Iterator[Tuple[str, str]]:
 
 
 def make_llm_state_dict(dims: BagelDims, seed: int = 0, device="cpu",
-                        include_lm_head: bool = False) -> Dict[str, torch.Tensor]:
+                        include_lm_head: bool = False, threads: int = 1) -> Dict[str, torch.Tensor]:
     """bf16 state dict of the language model + generation head.
 
     Matrices ~ N(0, 0.02); biases ~ N(0, 0.02); norm weights ~ N(1, 0.1) so that a
@@ -82,7 +82,8 @@ def make_llm_state_dict(dims: BagelDims, seed: int = 0, device="cpu",
     ``llm2vae`` (zero-initialised by the reference, bagel.py:97-100) is drawn
     with std 0.8/sqrt(hidden) so the velocity has RMS ~0.8 at every width, the
     scale of a real flow-matching velocity, which is what the absolute parity
-    tolerance on velocities presumes.
+    tolerance on velocities presumes.  ``threads`` > 1 draws the tensors in parallel
+    (same values: each tensor has its own seeded generator).
     """
     H, I, D = dims.hidden_size, dims.intermediate_size, dims.head_dim
     shapes = {
@@ -90,9 +91,26 @@ def make_llm_state_dict(dims: BagelDims, seed: int = 0, device="cpu",
         "wo": (H, dims.q_dim), "wi": (I, H), "wd": (H, I), "nd": (D,), "nh": (H,),
     }
     sd: Dict[str, torch.Tensor] = {}
+    jobs = []
 
     def put(name, shape, std, mean=0.0):
-        sd[name] = _randn(seed, name, shape, std, mean).to(device)
+        sd[name] = None                      # keeps the insertion order of the sequential generator
+        jobs.append((name, shape, std, mean))
+
+    def run_jobs():
+        # every tensor has its own generator, so the draws are independent of the order and of the thread that
+        # makes them; torch.randn releases the GIL
+        def one(job):
+            name, shape, std, mean = job
+            return name, _randn(seed, name, shape, std, mean).to(device)
+        if threads > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(threads) as ex:
+                for name, t in ex.map(one, jobs):
+                    sd[name] = t
+        else:
+            for job in jobs:
+                sd[job[0]] = one(job)[1]
 
     put("language_model.model.embed_tokens.weight", (dims.vocab_size, H), 0.02)
     for i in range(dims.num_layers):
@@ -115,6 +133,7 @@ def make_llm_state_dict(dims: BagelDims, seed: int = 0, device="cpu",
     put("vae2llm.bias", (H,), 0.02)
     put("llm2vae.weight", (P, H), 0.8 / H ** 0.5)
     put("llm2vae.bias", (P,), 0.02)
+    run_jobs()
     pe = get_2d_sincos_pos_embed(H, dims.max_latent_size)
     sd["latent_pos_embed.pos_embed"] = torch.from_numpy(pe).float().to(torch.bfloat16).to(device)
     return sd

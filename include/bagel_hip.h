@@ -197,6 +197,10 @@ typedef struct bagel_mot_rows {        /* one packed forward: activations, table
 
 #define BAGEL_LAYER_KV_ONLY 1  /* stop once the layer's keys/values are in K_ws / Vt_ws (last layer of a prefill) */
 #define BAGEL_LAYER_XN_READY 2 /* Xn already holds input_layernorm(X): the previous layer's call produced it */
+#define BAGEL_LAYER_UND_OUT_UNUSED 8 /* rows_gen > 0: nobody reads the understanding rows of X / Xn after this layer (last
+                                       layer of a generation forward, whose head takes the latent rows only,
+                                       bagel.py:1425-1426): their o_proj and MLP are skipped, their keys/values still
+                                       land in K_ws / Vt_ws; X and Xn of those rows are undefined on return */
 #define BAGEL_LAYER_NORM_IN_GEMM 4 /* rows_gen == 0, a few rows: both RMSNorms run inside the projections that consume
                                       them (bagel_skinny_gemm_rmsnorm_in_bf16); Xn is written only for next_norm_und */
 
@@ -228,7 +232,8 @@ int bagel_mot_layer_forward(const bagel_mot_dims* dims, const bagel_mot_layer* l
 /* All layers: layer l uses K_ws + l * layer_stride and Vt_ws + l * layer_stride (elements).  kv_only_last != 0
  * skips the last layer's attention and MLP (a context prefill only keeps keys/values).  Otherwise Xn holds
  * norm(X) (final_norm_gen on the first rows_gen rows, final_norm_und on the rest; first final_norm_rows rows
- * only when > 0) on return: Qwen2Model.norm / norm_moe_gen, qwen2_navit.py:1098-1105. */
+ * only when > 0) on return: Qwen2Model.norm / norm_moe_gen, qwen2_navit.py:1098-1105.  With 0 < final_norm_rows <=
+ * rows_gen the caller reads generation rows only and the last layer runs with BAGEL_LAYER_UND_OUT_UNUSED. */
 int bagel_mot_forward(const bagel_mot_dims* dims, const bagel_mot_layer* layers, int n_layers, const bagel_mot_rows* rows,
                       void* K_ws, void* Vt_ws, long layer_stride, int kv_only_last, const void* final_norm_gen,
                       const void* final_norm_und, int final_norm_rows, void* stream);

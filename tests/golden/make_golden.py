@@ -62,8 +62,10 @@ def save_index_tensors(out, tag, gi, extra=None):
 
 def run_llm_scenario(sc):
     t0 = time.time()
-    sd = make_llm_state_dict(sc.dims, seed=sc.weight_seed)
-    model = rh.build_reference_model(sc.dims, sd)
+    sd = make_llm_state_dict(sc.dims, seed=sc.weight_seed, threads=8)
+    big = sum(v.numel() for v in sd.values()) > 2e9     # the full-depth model: one copy of the weights only
+    model = rh.build_reference_model(sc.dims, sd, lean=big)
+    print(f"  [{sc.name}] model built at {time.time() - t0:.1f}s", flush=True)
     from modeling.bagel.qwen2_navit import NaiveCache
     tok = rh.StandInTokenizer()
     n = len(sc.images)
@@ -142,9 +144,11 @@ def run_llm_scenario(sc):
     # exact-arithmetic (fp32, no rounding points) evaluation of the same step by the CPU checker.
     from helpers import OracleRun
     noise = {}
-    exact = None if sc.enable_taylorseer else OracleRun(sc, exact=True)   # skipped steps have no per-step exact answer
+    # (skipped TaylorSeer steps have no per-step exact answer)
+    exact = None if sc.enable_taylorseer else OracleRun(sc, sd=sd if big else None, exact=True, lazy=big)
     for i, rec in enumerate(steps if exact is not None else []):
         vt, (c, x, m) = exact.step(i, rec["x_t"])
+        print(f"  [{sc.name}] exact step {i + 1} done at {time.time() - t0:.1f}s", flush=True)
         for key, t in (("v_cond", c), ("v_text", x), ("v_img", m), ("v_t", vt)):
             if key in rec:
                 out[f"step{i}.exact.{key}"] = t.float().clone()

@@ -78,8 +78,12 @@ class StandInTokenizer:
         return " ".join(str(int(i)) for i in ids)
 
 
-def build_reference_model(dims, state_dict):
-    """Reference ``Bagel`` (generation half only) carrying the given bf16 state dict."""
+def build_reference_model(dims, state_dict, lean=False):
+    """Reference ``Bagel`` (generation half only) carrying the given bf16 state dict.
+
+    ``lean``: the modules are constructed on the meta device and the state dict's tensors become the parameters
+    (``load_state_dict(assign=True)``), so a 28-layer model at BAGEL-7B width costs its 29 GB of bf16 weights
+    once instead of an fp32 initialisation (58 GB) plus the state dict.  Same parameter values either way."""
     _install_shims()
     from modeling.bagel.qwen2_navit import Qwen2Config, Qwen2ForCausalLM
     from modeling.bagel.bagel import Bagel, BagelConfig
@@ -112,6 +116,26 @@ def build_reference_model(dims, state_dict):
     config = BagelConfig(visual_gen=True, visual_und=dims.vit is not None, llm_config=llm_config, vit_config=vit_config,
                          vae_config=vae_config, latent_patch_size=dims.latent_patch_size,
                          max_latent_size=dims.max_latent_size, **extra)
+    if lean:
+        assert vit_model is None, "lean construction is for the generation half only"
+        with torch.device("meta"):
+            lm = Qwen2ForCausalLM(llm_config)
+            model = Bagel(lm, vit_model, config)
+        missing, unexpected = model.load_state_dict(state_dict, strict=False, assign=True)
+        missing = [m for m in missing if "lm_head" not in m]
+        assert not missing and not unexpected, (missing, unexpected)
+        model.language_model.lm_head = None          # never called by the generation path; still on meta
+        model = model.eval()
+        assert all(p.dtype == torch.bfloat16 and not p.is_meta for p in model.parameters())
+        # the rotary buffers were made on meta: same formula as the "default" rope initialiser above, fp32
+        rot = model.language_model.model.rotary_emb
+        D = dims.hidden_size // dims.num_heads
+        inv_freq = 1.0 / (dims.rope_theta ** (torch.arange(0, D, 2, dtype=torch.int64).float() / D))
+        rot.inv_freq = inv_freq
+        rot.original_inv_freq = inv_freq.clone()
+        leftovers = [n for n, b in model.named_buffers() if b.is_meta]
+        assert not leftovers, leftovers
+        return model
     lm = Qwen2ForCausalLM(llm_config)
     model = Bagel(lm, vit_model, config)
     missing, unexpected = model.load_state_dict(state_dict, strict=False)

@@ -88,26 +88,27 @@ def parity_stats(got: torch.Tensor, ref: torch.Tensor, exact: Optional[torch.Ten
 # ---- fixed parity bounds for per-step velocities --------------------------------------------------------
 # The stated bar is cosine >= 0.999 and max-abs <= 2e-2 against the reference.  One bf16 ulp is 1.6e-2 at |v| >= 2,
 # so two correct bf16 implementations that round at different points cannot meet 2e-2 on tensors whose elements
-# reach that size (every golden here: max |v| is 2.2 - 3.6); the reference itself sits 1.5e-2 ... 4.5e-2 (max) from
-# the exact-arithmetic answer.  The bar is therefore enforced as fixed numbers in three forms:
+# reach that size (every golden here: max |v| is 2.2 - 3.6); the reference itself sits 1.5e-2 ... 5e-2 (max) from
+# the exact-arithmetic answer.  Every golden file therefore carries the exact-arithmetic velocities of its steps
+# (``stepN.exact.*``; a file without them fails the check), and the bar is enforced as fixed numbers, the same for
+# every golden, all relative to the reference's OWN distance from exact arithmetic:
 #   (1) cosine >= 0.999 for every branch velocity;
 #   (2) closeness to exact arithmetic: the HIP result's mean distance to the exact answer is at most
-#       EXACT_RATIO_MEAN x the reference's own mean distance, and its max distance at most EXACT_RATIO_MAX x the
-#       reference's max distance (measured on MI355X: 1.000 - 1.028 and 1.01 - 1.31);
-#   (3) distance to the reference in bf16 ulps, per golden file: at least `frac2` of the elements within two ulps
-#       and none beyond `max_ulp` (ULP_BOUNDS; the numbers grow with depth because each layer adds a rounding).
+#       EXACT_RATIO_MEAN x the reference's mean distance, its max distance at most EXACT_RATIO_MAX x the
+#       reference's max distance (a kernel with twice the rounding noise reads 2.0 where 1.05 is allowed);
+#   (3) closeness to the reference: mean |hip - ref| <= REF_RATIO_MEAN x mean |ref - exact| and max |hip - ref| <=
+#       REF_RATIO_MAX x max |ref - exact|.  Two INDEPENDENT bf16 evaluations of the same graph with equal noise
+#       differ by sqrt(2) x that mean; the HIP path shares most rounding points with the reference and measures
+#       0.31 - 1.16, so 1.5 only admits a result at least as close to the reference as an independent re-evaluation;
+#   (4) the literal max-abs <= 2e-2 wherever a bf16 ulp is small enough for it to be meaningful (max |v| < 1).
 # The CFG-combined velocity v_t amplifies branch differences by up to (2 s_text - 1)(2 s_img - 1) = 14x, so for it
-# (2) and a looser cosine bound (0.995) apply: at 24 layers the reference's own combined velocity has cosine 0.9975
-# to the exact answer.
+# (2), (3) and a looser cosine bound (0.995) apply: at 24 layers the reference's own combined velocity has cosine
+# 0.9975 to the exact answer.  Distances in bf16 ulps are still logged (profiles/*_parity.json), not bounded.
 EXACT_RATIO_MEAN = 1.05
 EXACT_RATIO_MAX = 1.5
+REF_RATIO_MEAN = 1.5
+REF_RATIO_MAX = 2.0
 VT_COSINE = 0.995
-ULP_BOUNDS = {              # golden -> (min fraction within 2 ulp, max ulp); measured values in profiles/r02_parity.json
-    "gqa7_t2i": (0.96, 6.0),        # 2 layers, hidden 1792
-    "w7b_1024": (0.90, 8.0),        # 2 layers at BAGEL-7B width
-    "c1_0p5b_256": (0.55, 16.0),    # 24 layers
-}
-ULP_DEFAULT = (0.999, 4.0)          # the 2- and 3-layer tiny configurations
 
 PARITY_LOG = []          # rows appended by check_velocity; dumped by tests/conftest.py at session end
 
@@ -117,22 +118,36 @@ def check_velocity(got, golden: dict, key: str, what=""):
     ref = golden[key]
     step, name = key.split(".", 1)
     exact = golden.get(f"{step}.exact.{name}")
+    assert exact is not None, f"golden {what!r} holds no exact-arithmetic tensor for {key}: regenerate it with make_golden.py"
     st = parity_stats(got, ref, exact)
     PARITY_LOG.append({"golden": what, "tensor": key, **st})
     combined = name == "v_t"
     assert st["cosine"] >= (VT_COSINE if combined else V_COSINE), (what, key, "cosine", st["cosine"])
-    if not combined:
-        frac2, max_ulp = ULP_BOUNDS.get(what, ULP_DEFAULT)
-        if st["ref_max"] < 1.0:       # the literal bar, wherever a bf16 ulp is small enough for it to be meaningful
-            assert st["max_abs"] <= V_MAX_ABS, (what, key, "max-abs", st["max_abs"])
-        assert st["max_ulp"] <= max_ulp, (what, key, "max ulp", st["max_ulp"])
-        assert st["frac_le_2ulp"] >= frac2, (what, key, "fraction within 2 ulp", st["frac_le_2ulp"])
-    if exact is not None:
-        assert st["hip_vs_exact_mean"] <= EXACT_RATIO_MEAN * st["ref_vs_exact_mean"] + 1e-6, \
-            (what, key, "mean distance to exact", st["hip_vs_exact_mean"], st["ref_vs_exact_mean"])
-        assert st["hip_vs_exact_max"] <= EXACT_RATIO_MAX * st["ref_vs_exact_max"] + 1e-6, \
-            (what, key, "max distance to exact", st["hip_vs_exact_max"], st["ref_vs_exact_max"])
+    if not combined and st["ref_max"] < 1.0:
+        assert st["max_abs"] <= V_MAX_ABS, (what, key, "max-abs", st["max_abs"])
+    assert st["hip_vs_exact_mean"] <= EXACT_RATIO_MEAN * st["ref_vs_exact_mean"] + 1e-6, \
+        (what, key, "mean distance to exact", st["hip_vs_exact_mean"], st["ref_vs_exact_mean"])
+    assert st["hip_vs_exact_max"] <= EXACT_RATIO_MAX * st["ref_vs_exact_max"] + 1e-6, \
+        (what, key, "max distance to exact", st["hip_vs_exact_max"], st["ref_vs_exact_max"])
+    assert st["mean_abs"] <= REF_RATIO_MEAN * st["ref_vs_exact_mean"] + 1e-6, \
+        (what, key, "mean distance to the reference", st["mean_abs"], st["ref_vs_exact_mean"])
+    assert st["max_abs"] <= REF_RATIO_MAX * st["ref_vs_exact_max"] + 1e-6, \
+        (what, key, "max distance to the reference", st["max_abs"], st["ref_vs_exact_max"])
     return st["max_abs"], st["cosine"], st["mean_abs"]
+
+
+_SD_CACHE = {}
+
+
+def scenario_state_dict(dims, seed):
+    """The seeded bf16 weights of a scenario; the last one is kept, so that the tests of one big scenario (29 GB at
+    BAGEL-7B width and depth, drawn on several threads) generate it once."""
+    key = (dims, seed)
+    if key not in _SD_CACHE:
+        _SD_CACHE.clear()
+        big = dims.num_layers * dims.hidden_size * dims.intermediate_size > 1e9
+        _SD_CACHE[key] = make_llm_state_dict(dims, seed=seed, threads=8 if big else 1)
+    return _SD_CACHE[key]
 
 
 def oracle_context(sd, dims, prompts, n):
@@ -145,19 +160,28 @@ def oracle_context(sd, dims, prompts, n):
     return past, kvlens, ropes
 
 
+class UpcastOnRead(dict):
+    """A bf16 state dict whose tensors are handed out as fp32 copies, one at a time: the exact-arithmetic pass over a
+    28-layer model at BAGEL-7B width then needs its 29 GB of bf16 weights, not 58 GB of fp32 ones."""
+
+    def __getitem__(self, k):
+        return super().__getitem__(k).float()
+
+
 class OracleRun:
     """Everything the oracle needs to evaluate steps of a scenario.
 
-    ``exact=True`` evaluates in fp32 with no bf16 rounding points (exact-arithmetic answer).
+    ``exact=True`` evaluates in fp32 with no bf16 rounding points (exact-arithmetic answer); ``lazy`` keeps the
+    weights in bf16 and converts each tensor when it is read (same values, for models too big to hold twice).
     """
 
-    def __init__(self, sc: Scenario, sd: Optional[dict] = None, exact: bool = False):
+    def __init__(self, sc: Scenario, sd: Optional[dict] = None, exact: bool = False, lazy: bool = False):
         self.sc = sc
         self.dims = sc.dims
         self.exact = exact
-        self.sd = sd if sd is not None else make_llm_state_dict(sc.dims, seed=sc.weight_seed)
+        self.sd = sd if sd is not None else scenario_state_dict(sc.dims, sc.weight_seed)
         if exact:
-            self.sd = {k: v.float() for k, v in self.sd.items()}
+            self.sd = UpcastOnRead(self.sd) if lazy else {k: v.float() for k, v in self.sd.items()}
         n = len(sc.images)
         with torch.no_grad(), self._mode():
             self.ctx = {w: oracle_context(self.sd, sc.dims, sc.prompts(w), n) for w in ("cond", "text", "img")}

@@ -74,10 +74,23 @@ SCENARIOS = {s.name: s for s in [
     # BAGEL-7B width, 2 layers, 1024x1024, first two steps
     Scenario("w7b_1024", width7b_dims(2), [(1024, 1024)], [32], None, [32], num_timesteps=50,
              max_steps=2, slow=True),
+    # the benchmark's model: BAGEL-7B width AND depth (28 layers, 14.6 B parameters in the two experts), 1024x1024,
+    # first step with all three CFG branches
+    Scenario("w7b_l28_1024", width7b_dims(28), [(1024, 1024)], [32], None, [32], num_timesteps=50,
+             max_steps=1, slow=True),
     # plumbing configuration: Qwen2-0.5B-shaped MoT (head_dim 64), 256x256, 10 timesteps
     Scenario("c1_0p5b_256", BagelDims(hidden_size=896, intermediate_size=4864, num_layers=24, num_heads=14,
                                        num_kv_heads=2, vocab_size=2048),
              [(256, 256)], [16], None, [16], num_timesteps=10, slow=True),
+]}
+
+
+# Scenarios without a golden file (compared between configurations of the HIP path itself)
+EXTRA_SCENARIOS = {s.name: s for s in [
+    # 12 samples x 3 branches = 36 units in one packed forward: 72 text rows, more than one 64-row launch of the
+    # understanding expert's weight-streaming kernel; two ranks hold 18 units (36 text rows) each
+    Scenario("tiny_batch12", tiny_dims(2), [(64, 64), (96, 64), (64, 128)] * 4, [5, 9, 3] * 4, [2, 4, 7] * 4, [5, 9, 3] * 4,
+             num_timesteps=4, cfg_interval=(0.0, 1.0)),
 ]}
 
 

@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests.helpers import OracleRun, load_golden, have_golden, metrics, check_velocity  # noqa: E402
+from tests.helpers import OracleRun, load_golden, have_golden, metrics, check_velocity, scenario_state_dict  # noqa: E402
 from tests.scenarios import SCENARIOS  # noqa: E402
 from tests.gpu_common import run_scenario_on_gpu  # noqa: E402
 
@@ -67,6 +67,41 @@ def test_free_running_sampler_final_latent():
     out = run_scenario_on_gpu(sc, OracleRun(sc))
     ma, cos = metrics(torch.cat(list(out)), g["final_latent"])
     assert cos >= 0.999 and ma <= 0.15, (ma, cos)
+
+
+def test_free_running_sampler_24_layers_latent_and_image():
+    """The plumbing configuration (24 layers, head_dim 64, 256 x 256, 10 timesteps) run FREE through all nine Euler
+    steps: the final latent against the reference's, and both latents decoded by the same HIP VAE decoder against each
+    other as 8-bit images.  Bar: PSNR >= 40 dB (and the latent's cosine)."""
+    import numpy as np
+    from bagel_amd.config import VAEDims
+    from bagel_amd.modeling import AutoEncoder
+    from bagel_amd.weights import make_vae_decoder_state_dict
+    from oracle import bagel_oracle as O
+    name = "c1_0p5b_256"
+    sc = SCENARIOS[name]
+    g = load_golden(name)
+    assert "final_latent" in g
+    out = torch.cat(list(run_scenario_on_gpu(sc, OracleRun(sc))))
+    ref = g["final_latent"]
+    ma, cos = metrics(out, ref)
+    rel = float((out.cpu().float() - ref.float()).norm() / ref.float().norm())
+    vd = VAEDims()
+    ae = AutoEncoder(vd, make_vae_decoder_state_dict(vd, seed=0), "cuda:0")
+
+    def image(latent):
+        z = O.unpatchify_latent(sc.dims, latent.detach().float().cpu(), sc.images[0]).to("cuda:0")
+        return O.to_uint8_image(ae.decode(z).float().cpu()).numpy().astype(np.float32)
+
+    a, b = image(out), image(ref)
+    mse = float(((a - b) ** 2).mean())
+    p = 10 * np.log10(255.0 ** 2 / max(mse, 1e-12))
+    print(f"{name} free-running: final latent max-abs {ma:.4f} cosine {cos:.6f} relative L2 {rel:.4f}; image PSNR {p:.1f} dB")
+    from tests.helpers import PARITY_LOG
+    PARITY_LOG.append({"golden": name, "tensor": "final_latent (9 free Euler steps)", "max_abs": ma, "cosine": cos,
+                       "relative_l2": rel, "image_psnr_db": float(p)})
+    assert cos >= 0.999, (ma, cos)
+    assert p >= 40.0, p
 
 
 def test_matches_cpu_checker_on_fresh_inputs():
@@ -147,7 +182,7 @@ class _Tok:
         return [int(t) for t in text.split()]
 
 
-@pytest.mark.parametrize("name", ["tiny_t2i", "tiny_edit3", "tiny_batch2", "gqa7_t2i", "w7b_1024"])
+@pytest.mark.parametrize("name", ["tiny_t2i", "tiny_edit3", "tiny_batch2", "gqa7_t2i", "w7b_1024", "w7b_l28_1024"])
 def test_text_prefill_matches_reference(name):
     """Bagel.prepare_prompts + forward_cache_update_text (causal und-mode prefill on HIP kernels) against
     the context keys/values the reference produced for the cond branch."""
@@ -156,8 +191,7 @@ def test_text_prefill_matches_reference(name):
     from bagel_amd.modeling import NaiveCache
     sc = SCENARIOS[name]
     g = load_golden(name)
-    from bagel_amd.weights import make_llm_state_dict
-    model = gpu_model(sc, make_llm_state_dict(sc.dims, seed=sc.weight_seed))
+    model = gpu_model(sc, scenario_state_dict(sc.dims, sc.weight_seed))
     prompts = sc.prompts("cond")
     n = len(prompts)
     gi, newlens, newrope = model.prepare_prompts([0] * n, [0] * n, [" ".join(map(str, p)) for p in prompts], _Tok(),
@@ -213,7 +247,7 @@ def test_inferencer_text_to_image_end_to_end():
     import numpy as np
     sc = SCENARIOS["tiny_t2i"]
     g = load_golden("tiny_t2i")
-    model = gpu_model(sc, make_llm_state_dict(sc.dims, seed=sc.weight_seed))
+    model = gpu_model(sc, scenario_state_dict(sc.dims, sc.weight_seed))
     vd = VAEDims()
     vsd = make_vae_decoder_state_dict(vd, seed=0)
     inf = InterleaveInferencer(model, AutoEncoder(vd, vsd, "cuda:0"), _Tok(), None, None, NEW_TOKEN_IDS)

@@ -16,12 +16,12 @@ def _worker(rank, world, port, name, q):
     import torch.distributed as dist
     from tests.gpu_common import run_scenario_on_gpu
     from tests.helpers import OracleRun
-    from tests.scenarios import SCENARIOS, TAYLOR_SCENARIOS
+    from tests.scenarios import SCENARIOS, TAYLOR_SCENARIOS, EXTRA_SCENARIOS
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        sc = {**SCENARIOS, **TAYLOR_SCENARIOS}[name]
+        sc = {**SCENARIOS, **TAYLOR_SCENARIOS, **EXTRA_SCENARIOS}[name]
         calls = []
         real = dist.all_gather_into_tensor
 
@@ -40,14 +40,16 @@ def _worker(rank, world, port, name, q):
 
 
 @pytest.mark.parametrize("name,world", [("tiny_batch2", 2), ("tiny_edit3", 2), ("tiny_t2i", 2), ("tiny_t2i", 3),
-                                        ("tiny_textcfg", 2), ("tiny_taylor", 2)])
+                                        ("tiny_textcfg", 2), ("tiny_taylor", 2), ("tiny_batch12", 2)])
 def test_ranks_reproduce_one(name, world):
     """tiny_t2i has cond-only steps (outside the CFG interval) in which all ranks but one own no unit at all;
-    tiny_edit3 splits one image's three branches 2 + 1; tiny_textcfg has two branches per sample."""
+    tiny_edit3 splits one image's three branches 2 + 1; tiny_textcfg has two branches per sample; tiny_batch12 packs
+    36 units = 72 text rows into the single process's forward (more than one 64-row launch of the understanding
+    expert's weight-streaming kernel) against 36 rows per rank."""
     from tests.gpu_common import run_scenario_on_gpu
     from tests.helpers import OracleRun
-    from tests.scenarios import SCENARIOS, TAYLOR_SCENARIOS
-    sc = {**SCENARIOS, **TAYLOR_SCENARIOS}[name]
+    from tests.scenarios import SCENARIOS, TAYLOR_SCENARIOS, EXTRA_SCENARIOS
+    sc = {**SCENARIOS, **TAYLOR_SCENARIOS, **EXTRA_SCENARIOS}[name]
     base = [x.float().cpu() for x in run_scenario_on_gpu(sc, OracleRun(sc))]
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
