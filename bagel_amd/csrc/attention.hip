@@ -26,6 +26,13 @@
 // fp32 accumulation, division by the fp32 row sum at the end.
 #include "common.h"
 
+#ifndef ATTN_QK_RING
+#define ATTN_QK_RING 3      // key fragments in flight ahead of the score products
+#endif
+#ifndef ATTN_PIN
+#define ATTN_PIN 2          // 1: pin the product / read alternation with sched_group_barrier
+#endif
+
 struct AttnTile {
   int q_row0;       // first query row (row index into Q / O)
   int n_rows;       // valid rows in this tile (<= 128)
@@ -120,42 +127,39 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 3) void attention_kernel(AttnParams
       (void*)(p.K + ((long)kvh * p.S + t.kv_start) * HD), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.Vt + (long)kvh * HD * p.S + t.kv_start), 0, 0x7fffffff, 0x00020000);
-  int k_voff[K_IT], v_voff[V_IT];
-#pragma unroll
-  for (int it = 0; it < K_IT; ++it) {
-    const int krow = (it * 4 + wave) * K_RPP + lane / K_CH;
-    k_voff[it] = (krow * HD + (((lane % K_CH) ^ k_swz(krow)) * 8)) * 2;
-  }
-#pragma unroll
-  for (int it = 0; it < V_IT; ++it) {
-    const int vrow = (it * 4 + wave) * 8 + (lane >> 3);
-    v_voff[it] = (int)(((long)vrow * p.S + (((lane & 7) ^ ((vrow >> 1) & 7)) * 8)) * 2);
-  }
+  // A wave's pieces of a tile are 16 (HD 128) or 32 (HD 64) key rows, resp. 32 value rows, apart: the XOR swizzle of
+  // the lane's row is the same for each of them, so ONE lane offset per operand serves every piece and the piece's
+  // distance (4 KiB of keys, 32 rows of S values) rides in the scalar offset beside the tile offset.
+  const int krow0 = wave * K_RPP + lane / K_CH;
+  const int k_voff = (krow0 * HD + (((lane % K_CH) ^ k_swz(krow0)) * 8)) * 2;
+  const int vrow0 = wave * 8 + (lane >> 3);
+  const int v_voff = (int)(((long)vrow0 * p.S + (((lane & 7) ^ ((vrow0 >> 1) & 7)) * 8)) * 2);
+  const int v_piece = (int)(64 * p.S);     // bytes between a wave's consecutive Vt pieces (32 rows)
+  auto stage_k_piece = [&](int kt, int buf, int it) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LDS_PTR(smem + buf * STAGE + (it * 4 + wave) * 1024), 16, k_voff,
+                                             kt * (KT * HD * 2) + it * 4096, 0, 0);
+  };
+  auto stage_v_piece = [&](int kt, int buf, int it) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LDS_PTR(smem + buf * STAGE + K_BYTES + (it * 4 + wave) * 1024), 16,
+                                             v_voff, kt * (KT * 2) + it * v_piece, 0, 0);
+  };
   auto stage_k = [&](int kt, int buf) {
-    char* base = smem + buf * STAGE;
 #pragma unroll
-    for (int it = 0; it < K_IT; ++it)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LDS_PTR(base + (it * 4 + wave) * 1024), 16, k_voff[it],
-                                               kt * (KT * HD * 2), 0, 0);
+    for (int it = 0; it < K_IT; ++it) stage_k_piece(kt, buf, it);
   };
   auto stage_v = [&](int kt, int buf) {
-    char* base = smem + buf * STAGE + K_BYTES;
 #pragma unroll
-    for (int it = 0; it < V_IT; ++it)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LDS_PTR(base + (it * 4 + wave) * 1024), 16, v_voff[it],
-                                               kt * (KT * 2), 0, 0);
+    for (int it = 0; it < V_IT; ++it) stage_v_piece(kt, buf, it);
   };
 
   // ---- fragment read offsets
-  // K: A-operand row i of a 32-key block is key pi(i) (bits 2,3 swapped)
+  // K: A-operand row i of a 32-key block is key pi(i) (bits 2,3 swapped).  The 16-byte chunk (2 ks + h) of that row
+  // sits at chunk ^ swizzle(row), i.e. at byte (base of the row | (h ^ swizzle) << 4) ^ (ks << 5): one address
+  // register and one XOR per read instead of one register per k step.
   const int pi = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
-  int k_off[2];  // per 32-key block; chunk XOR depends on ks
-  k_off[0] = pi * (HD * 2);
-  k_off[1] = (32 + pi) * (HD * 2);
-  const int k_sw = k_swz(pi);  // the same for both 32-key blocks
-  // Vt: row d = db*32 + l31; swizzle ((row >> 1) & 7) is the same for every db (32 | row offset)
-  const int v_row_off = l31 * (KT * 2);
-  const int v_sw = (l31 >> 1) & 7;
+  const int k_a0 = pi * (HD * 2) + ((h ^ k_swz(pi)) << 4);
+  // Vt: row d = db*32 + l31; chunk 2 j + h of the row (j = 16-key step of the tile) at (... | (h ^ swizzle) << 4) ^ (j << 5)
+  const int v_a0 = l31 * (KT * 2) + ((h ^ ((l31 >> 1) & 7)) << 4);
 
   f32x16 o_acc[DB];
 #pragma unroll
@@ -200,32 +204,57 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 3) void attention_kernel(AttnParams
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // S^T for two 32-key blocks
+    // S^T for two 32-key blocks.  The 2 KS key fragments go through a ring of RING registers quads: fragment
+    // i + RING is requested right behind the product that consumed fragment i, so a product never waits for a read
+    // issued just before it.  The addresses are re-derived from one register per tile (the empty asm keeps the
+    // compiler from holding 2 KS of them across the loop, which is what forced it to read one fragment at a time).
     f32x16 s[2];
-    // The first block's K fragments are requested before the values' DMA is issued (the compiler keeps
-    // LDS reads and LDS-DMA in program order), so their latency passes under the DMA issue; the second
-    // block's are requested while the first block's products run.
-    bf16x8 kf0[KS], kf1[KS];
+    int k_a = k_a0;
+    asm volatile("" : "+v"(k_a));
+    constexpr int RING = ATTN_QK_RING;
+    bf16x8 kf[RING];
+    auto kread = [&](int i) {
+      return *(const bf16x8*)(kb + (i / KS) * (32 * HD * 2) + (k_a ^ ((i % KS) << 5)));
+    };
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kf0[ks] = *(const bf16x8*)(kb + k_off[0] + (((2 * ks + h) ^ k_sw) * 16));
+    for (int i = 0; i < RING; ++i) kf[i] = kread(i);
+#if ATTN_PIN == 2
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if constexpr (DEEP) {
       if (kt + 1 < n_kt) {
         stage_k(kt + 1, (kt + 1) & 1);
         stage_v(kt + 1, (kt + 1) & 1);
       }
-    } else {
-      stage_v(kt, 0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[0][r] = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[1][r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kf1[ks] = *(const bf16x8*)(kb + k_off[1] + (((2 * ks + h) ^ k_sw) * 16));
+    for (int i = 0; i < 2 * KS; ++i) {
+      s[i / KS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % RING], qf[i % KS], s[i / KS], 0, 0, 0);
+      if (i + RING < 2 * KS) kf[i % RING] = kread(i + RING);
+      // the values' DMA pieces go out one by one between the products (LDS reads and LDS-DMA keep program order)
+      if constexpr (!DEEP)
+        if (i % 2 == 1 && i / 2 < V_IT) stage_v_piece(kt, 0, i / 2);
+#if ATTN_PIN == 2
+      // The scheduler, left alone, sinks every read to just before its product to save registers, and each product
+      // then waits out a whole LDS round trip: nothing may cross from one product / piece / read group to the next.
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+#if ATTN_PIN == 1
+    // The order above, told to the scheduler (left alone it sinks every read to just before its product to save
+    // registers, and each product then waits out a whole LDS round trip): RING reads, then product, [DMA piece], read.
+    __builtin_amdgcn_sched_group_barrier(0x100, RING, 0);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], s[0], 0, 0, 0);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], s[1], 0, 0, 0);
+    for (int i = 0; i < 2 * KS; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (!DEEP && i % 2 == 1 && i / 2 < V_IT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if (i + RING < 2 * KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#endif
     // mask the tail keys of the last tile (raw scores; the softmax scale is folded into the exponent)
     const int key0 = kt * KT;
     const bool tail = key0 + KT > (causal ? t.causal_base + wave * 32 + 1 : kv_len);  // wave-uniform
@@ -274,6 +303,8 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 3) void attention_kernel(AttnParams
       if (kt + 1 < n_kt) stage_k(kt + 1, 0);
     }
     const float neg_m = m_run == -INFINITY ? 0.f : -m_run;
+    int v_a = v_a0;
+    asm volatile("" : "+v"(v_a));
     float psum = 0.f;
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -293,10 +324,9 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 3) void attention_kernel(AttnParams
         bf16x8 pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (bf16)s[b][8 * st + j];
-        const int chunk = 2 * (2 * b + st) + h;
 #pragma unroll
         for (int d = 0; d < DB; ++d) {
-          const bf16x8 vf = *(const bf16x8*)(vb + d * 32 * (KT * 2) + v_row_off + ((chunk ^ v_sw) * 16));
+          const bf16x8 vf = *(const bf16x8*)(vb + d * 32 * (KT * 2) + (v_a ^ ((2 * b + st) << 5)));
           o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[d], 0, 0, 0);
         }
       }

@@ -55,22 +55,40 @@ extern "C" int bagel_conv3x3_nhwc_bf16(const void* x, int Hin, int Win, int Cin,
 
 // -------------------------------------------------------------------------------------------------
 // GroupNorm(32 groups, eps) [+ swish] on NHWC bf16.  nn.GroupNorm at autoencoder.py:43,75,77,247 and
-// swish (:34-35).  Statistics in fp32 per (group) over H*W*C/32 values; three passes:
-// partial sums per block -> per-group mean/rstd -> y = swish((x - mean) * rstd * gamma + beta) -> bf16.
+// swish (:34-35).  Statistics per group over H*W*C/32 values (fp32 partial sums per block, fp64 across blocks);
+// three passes: partial sums per block -> per-channel scale = rstd * gamma, shift = beta - mean * scale ->
+// y = swish(x * scale + shift) -> bf16.
 // -------------------------------------------------------------------------------------------------
 constexpr int GN_BLOCKS = 512;
 
+// Pass 1: every thread owns one 8-channel chunk (the same one in every iteration: the block's pixel stride is a
+// whole number of rows) and walks pixels with four 16-byte loads in flight.
 __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16* __restrict__ x, long npix, int C,
                                                          float* __restrict__ part) {
-  // thread owns one 8-channel chunk; consecutive threads cover consecutive chunks of a pixel (coalesced)
   const int cpr = C / 8;
   const int chunk = threadIdx.x % cpr;
   const int ppb = 256 / cpr;  // pixels per block-iteration
   float s[8], q[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-  for (long pix = (long)blockIdx.x * ppb + threadIdx.x / cpr; pix < npix; pix += (long)gridDim.x * ppb) {
-    const bf16x8 v = *(const bf16x8*)(x + pix * C + chunk * 8);
+  const long stride = (long)gridDim.x * ppb;
+  const bf16* src = x + chunk * 8;
+  long pix = (long)blockIdx.x * ppb + threadIdx.x / cpr;
+  for (; pix + 3 * stride < npix; pix += 4 * stride) {
+    bf16x8 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *(const bf16x8*)(src + (pix + u * stride) * C);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)      // the same order of additions as one pixel per iteration
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = (float)v[u][e];
+        s[e] += f;
+        q[e] += f * f;
+      }
+  }
+  for (; pix < npix; pix += stride) {
+    const bf16x8 v = *(const bf16x8*)(src + pix * C);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float f = (float)v[e];
@@ -97,74 +115,109 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16* __restrict_
   }
 }
 
-// 32 groups x 32 lanes: lane l of group g sums the partial blocks l, l + 32, ... in fp64, the group's lanes are
-// then combined through LDS in a fixed order.
-__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long npix,
-                                                           float eps, float* __restrict__ stats) {
-  const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
-  const int cpg = C / 32;
+// Pass 2: one workgroup per group.  Thread t sums the (block, channel) partials t, t + 256, ... of its group in
+// fp64; the 256 sums are then combined through LDS in a fixed order, so the statistics do not depend on timing.
+// Output per channel: scale = rstd * gamma and shift = beta - mean * scale (what pass 3 applies).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long npix,
+                                                           float eps, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ scale_shift) {
+  const int g = blockIdx.x, cpg = C / 32;
   double s = 0.0, q = 0.0;
-  for (int b = l; b < nblocks; b += 32)
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-      s += part[((long)b * C + c) * 2];
-      q += part[((long)b * C + c) * 2 + 1];
-    }
-  __shared__ double sh_s[32][33], sh_q[32][33];
-  sh_s[g][l] = s;
-  sh_q[g][l] = q;
-  __syncthreads();
-  if (l != 0) return;
-  s = q = 0.0;
-  for (int i = 0; i < 32; ++i) {
-    s += sh_s[g][i];
-    q += sh_q[g][i];
+  const int n = nblocks * cpg;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int b = i / cpg, c = g * cpg + i - b * cpg;
+    const float2 v = *(const float2*)(part + ((long)b * C + c) * 2);
+    s += v.x;
+    q += v.y;
   }
-  const double n = (double)npix * cpg;
-  const double mean = s / n;
-  const double var = q / n - mean * mean;
-  stats[2 * g] = (float)mean;
-  stats[2 * g + 1] = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)eps));
+  __shared__ double sh_s[256], sh_q[256];
+  __shared__ float sh_stat[2];
+  sh_s[threadIdx.x] = s;
+  sh_q[threadIdx.x] = q;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) {
+      sh_s[threadIdx.x] += sh_s[threadIdx.x + w];
+      sh_q[threadIdx.x] += sh_q[threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double cnt = (double)npix * cpg;
+    const double mean = sh_s[0] / cnt;
+    const double var = sh_q[0] / cnt - mean * mean;
+    sh_stat[0] = (float)mean;
+    sh_stat[1] = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)eps));
+  }
+  __syncthreads();
+  for (int c = g * cpg + threadIdx.x; c < (g + 1) * cpg; c += 256) {
+    const float sc = sh_stat[1] * gamma[c];
+    scale_shift[2 * c] = sc;
+    scale_shift[2 * c + 1] = beta[c] - sh_stat[0] * sc;
+  }
 }
 
+// Pass 3: y = swish(x * scale + shift).  A thread keeps the scale / shift of its 8 channels in registers and walks
+// pixels with four 16-byte loads in flight (a block's pixel stride is a whole number of rows, so the chunk is fixed).
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ x, long npix, int C,
-                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, int swish, bf16* __restrict__ out) {
+                                                       const float* __restrict__ scale_shift, int swish,
+                                                       bf16* __restrict__ out) {
   const int cpr = C / 8;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= npix * cpr) return;
-  const int chunk = idx % cpr;
-  const int cpg = C / 32;
-  const bf16x8 v = *(const bf16x8*)(x + idx * 8);
-  bf16x8 o;
+  const int chunk = threadIdx.x % cpr;
+  const int ppb = 256 / cpr;
+  float a[8], b[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const int c = chunk * 8 + e;
-    const int g = c / cpg;
-    float y = ((float)v[e] - stats[2 * g]) * stats[2 * g + 1] * gamma[c] + beta[c];
-    if (swish) y = y / (1.0f + __expf(-y));
-    o[e] = (bf16)y;
+    const float2 ss = *(const float2*)(scale_shift + 2 * (chunk * 8 + e));
+    a[e] = ss.x;
+    b[e] = ss.y;
   }
-  *(bf16x8*)(out + idx * 8) = o;
+  auto apply = [&](const bf16x8 v) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float y = __builtin_fmaf((float)v[e], a[e], b[e]);
+      if (swish) y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+      o[e] = (bf16)y;
+    }
+    return o;
+  };
+  const long stride = (long)gridDim.x * ppb;
+  const long off = chunk * 8;
+  long pix = (long)blockIdx.x * ppb + threadIdx.x / cpr;
+  for (; pix + 3 * stride < npix; pix += 4 * stride) {
+    bf16x8 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *(const bf16x8*)(x + (pix + u * stride) * C + off);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *(bf16x8*)(out + (pix + u * stride) * C + off) = apply(v[u]);
+  }
+  for (; pix < npix; pix += stride) *(bf16x8*)(out + pix * C + off) = apply(*(const bf16x8*)(x + pix * C + off));
 }
 
-extern "C" long bagel_groupnorm_workspace_bytes(int C) { return ((long)GN_BLOCKS * C * 2 + 64) * sizeof(float); }
+extern "C" long bagel_groupnorm_workspace_bytes(int C) { return ((long)GN_BLOCKS * C * 2 + 2L * C) * sizeof(float); }
 
 extern "C" int bagel_groupnorm_swish_nhwc_bf16(const void* x, long npix, int C, const void* gamma_f32,
                                                const void* beta_f32, float eps, int swish, void* out, void* workspace,
                                                long workspace_bytes, void* stream) {
   BAGEL_CHECK(x && gamma_f32 && beta_f32 && out && workspace, "bagel_groupnorm_swish_nhwc_bf16: null operand");
   BAGEL_CHECK(C % 32 == 0 && C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0, "bagel_groupnorm_swish_nhwc_bf16: C=%d not supported", C);
+  BAGEL_CHECK(npix > 0, "bagel_groupnorm_swish_nhwc_bf16: empty image");
   BAGEL_CHECK(workspace_bytes >= bagel_groupnorm_workspace_bytes(C), "bagel_groupnorm_swish_nhwc_bf16: workspace too small");
+  BAGEL_CHECK(((uintptr_t)x | (uintptr_t)out | (uintptr_t)workspace) % 16 == 0, "bagel_groupnorm_swish_nhwc_bf16: misaligned operand");
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;
-  float* stats = part + (long)GN_BLOCKS * C * 2;
+  float* scale_shift = part + (long)GN_BLOCKS * C * 2;
   const int ppb = 256 / (C / 8);
-  const int nblocks = (int)((npix + ppb - 1) / ppb < GN_BLOCKS ? (npix + ppb - 1) / ppb : GN_BLOCKS);
+  const long rows = (npix + ppb - 1) / ppb;     // block-iterations the image holds
+  const int nblocks = (int)(rows < GN_BLOCKS ? rows : GN_BLOCKS);
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nblocks), dim3(256), 0, st, (const bf16*)x, npix, C, part);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nblocks, C, npix, eps, stats);
-  const long n = npix * (C / 8);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const bf16*)x, npix, C, stats,
-                     (const float*)gamma_f32, (const float*)beta_f32, swish, (bf16*)out);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(32), dim3(256), 0, st, part, nblocks, C, npix, eps, (const float*)gamma_f32,
+                     (const float*)beta_f32, scale_shift);
+  // eight workgroups per CU when the image is large enough; each thread then streams four pixels at a time
+  const long want = (rows + 3) / 4;
+  const int ablocks = (int)(want < 8L * bagel_cu_count() ? (want > 0 ? want : 1) : 8L * bagel_cu_count());
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(ablocks), dim3(256), 0, st, (const bf16*)x, npix, C, scale_shift, swish, (bf16*)out);
   BAGEL_LAUNCH_CHECK();
   return 0;
 }

@@ -156,6 +156,13 @@ def run_llm_scenario(sc):
                 d = (a - b).abs()
                 noise[f"step{i}.{key}"] = [float(d.max()), float(d.mean()),
                                            float(torch.dot(a, b) / (a.norm() * b.norm()))]
+    if exact is not None and "cond_ctx.k0" in out:      # the prefill's exact-arithmetic keys/values, same layers
+        xk = exact.ctx["cond"][0]
+        last = sc.dims.num_layers - 1
+        out["cond_ctx.exact.k0"] = xk.key_cache[0].float().clone()
+        out["cond_ctx.exact.v0"] = xk.value_cache[0].float().clone()
+        out["cond_ctx.exact.k_last"] = xk.key_cache[last].float().clone()
+        out["cond_ctx.exact.v_last"] = xk.value_cache[last].float().clone()
     if noise:
         print(f"  [{sc.name}] reference-vs-exact noise floor: max {max(v[0] for v in noise.values()):.4f} "
               f"mean {max(v[1] for v in noise.values()):.5f}")

@@ -81,7 +81,8 @@ def parity_stats(got: torch.Tensor, ref: torch.Tensor, exact: Optional[torch.Ten
         x = exact.detach().float().cpu().flatten()
         he, re_ = (g - x).abs(), (r - x).abs()
         out.update({"hip_vs_exact_max": float(he.max()), "hip_vs_exact_mean": float(he.mean()),
-                    "ref_vs_exact_max": float(re_.max()), "ref_vs_exact_mean": float(re_.mean())})
+                    "ref_vs_exact_max": float(re_.max()), "ref_vs_exact_mean": float(re_.mean()),
+                    "ref_vs_exact_cosine": float(torch.dot(r, x) / (r.norm() * x.norm() + 1e-30))})
     return out
 
 
@@ -102,8 +103,10 @@ def parity_stats(got: torch.Tensor, ref: torch.Tensor, exact: Optional[torch.Ten
 #       0.31 - 1.16, so 1.5 only admits a result at least as close to the reference as an independent re-evaluation;
 #   (4) the literal max-abs <= 2e-2 wherever a bf16 ulp is small enough for it to be meaningful (max |v| < 1).
 # The CFG-combined velocity v_t amplifies branch differences by up to (2 s_text - 1)(2 s_img - 1) = 14x, so for it
-# (2), (3) and a looser cosine bound (0.995) apply: at 24 layers the reference's own combined velocity has cosine
-# 0.9975 to the exact answer.  Distances in bf16 ulps are still logged (profiles/*_parity.json), not bounded.
+# (2), (3) and a cosine bound tied to the reference's own apply: two evaluations that each sit at cosine c from the
+# exact answer with independent errors sit at 1 - 2 (1 - c) from each other, so the bound is the smaller of 0.995 and
+# 1 - 2.5 (1 - c) (the reference's own combined velocity has c = 0.9975 at 24 layers and 0.9866 at 28 layers of
+# BAGEL-7B width).  Distances in bf16 ulps are still logged (profiles/*_parity.json), not bounded.
 EXACT_RATIO_MEAN = 1.05
 EXACT_RATIO_MAX = 1.5
 REF_RATIO_MEAN = 1.5
@@ -122,7 +125,8 @@ def check_velocity(got, golden: dict, key: str, what=""):
     st = parity_stats(got, ref, exact)
     PARITY_LOG.append({"golden": what, "tensor": key, **st})
     combined = name == "v_t"
-    assert st["cosine"] >= (VT_COSINE if combined else V_COSINE), (what, key, "cosine", st["cosine"])
+    cos_bound = min(VT_COSINE, 1.0 - 2.5 * (1.0 - st["ref_vs_exact_cosine"])) if combined else V_COSINE
+    assert st["cosine"] >= cos_bound, (what, key, "cosine", st["cosine"], cos_bound)
     if not combined and st["ref_max"] < 1.0:
         assert st["max_abs"] <= V_MAX_ABS, (what, key, "max-abs", st["max_abs"])
     assert st["hip_vs_exact_mean"] <= EXACT_RATIO_MEAN * st["ref_vs_exact_mean"] + 1e-6, \
@@ -134,6 +138,24 @@ def check_velocity(got, golden: dict, key: str, what=""):
     assert st["max_abs"] <= REF_RATIO_MAX * st["ref_vs_exact_max"] + 1e-6, \
         (what, key, "max distance to the reference", st["max_abs"], st["ref_vs_exact_max"])
     return st["max_abs"], st["cosine"], st["mean_abs"]
+
+
+def check_tensor_vs_reference(got, ref, exact, what="", key="", cosine=V_COSINE):
+    """The same relative bars for any bf16 tensor the golden file holds with its exact-arithmetic twin (context
+    keys / values of a prefill): cosine, distance to exact arithmetic against the reference's own, distance to the
+    reference against the reference's distance to exact."""
+    st = parity_stats(got, ref, exact)
+    PARITY_LOG.append({"golden": what, "tensor": key, **st})
+    assert st["cosine"] >= cosine, (what, key, "cosine", st["cosine"])
+    assert st["hip_vs_exact_mean"] <= EXACT_RATIO_MEAN * st["ref_vs_exact_mean"] + 1e-6, \
+        (what, key, "mean distance to exact", st["hip_vs_exact_mean"], st["ref_vs_exact_mean"])
+    assert st["hip_vs_exact_max"] <= EXACT_RATIO_MAX * st["ref_vs_exact_max"] + 1e-6, \
+        (what, key, "max distance to exact", st["hip_vs_exact_max"], st["ref_vs_exact_max"])
+    assert st["mean_abs"] <= REF_RATIO_MEAN * st["ref_vs_exact_mean"] + 1e-6, \
+        (what, key, "mean distance to the reference", st["mean_abs"], st["ref_vs_exact_mean"])
+    assert st["max_abs"] <= REF_RATIO_MAX * st["ref_vs_exact_max"] + 1e-6, \
+        (what, key, "max distance to the reference", st["max_abs"], st["ref_vs_exact_max"])
+    return st
 
 
 _SD_CACHE = {}

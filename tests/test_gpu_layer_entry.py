@@ -60,9 +60,16 @@ def _per_op_layer(K, w, X, Kw, Vt, cos, sin, row_cs, row_slot, tiles, n_tiles, S
     tile = Mv == 0 and Mt > 16      # no generation rows: the tile kernels from 17 rows on, norms in the reduce launches
 
     def und(x, wt, out, **kw):
-        if x.shape[0] <= 64 and not tile:
+        if not tile:
+            # beside generation rows the understanding rows keep the weight-streaming kernel, 64 rows per launch
+            # (bits independent of the row count)
             ep = {None: K.SK_BIAS, "residual": K.SK_RESIDUAL, "swiglu": K.SK_SWIGLU}[kw.pop("kind", None)]
-            return K.skinny_gemm(x, wt, out, skw, epilogue=ep, **kw)
+            res = kw.pop("residual", None)
+            for r0 in range(0, x.shape[0], 64):
+                r1 = min(r0 + 64, x.shape[0])
+                extra = dict(kw, residual=res[r0:r1]) if res is not None else kw
+                K.skinny_gemm(x[r0:r1], wt, out[r0:r1], skw, epilogue=ep, **extra)
+            return
         ep = {None: K.EPI_BIAS, "residual": K.EPI_RESIDUAL, "swiglu": K.EPI_SWIGLU}[kw.pop("kind", None)]
         return K.gemm(x, wt, out, epilogue=ep, workspace=skw, **kw)
 

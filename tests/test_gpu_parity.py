@@ -199,12 +199,14 @@ def test_text_prefill_matches_reference(name):
     assert newlens == [len(p) + 2 for p in prompts] and newrope == newlens
     past = model.forward_cache_update_text(NaiveCache(sc.dims.num_layers), **gi)
     last = sc.dims.num_layers - 1
+    from tests.helpers import check_tensor_vs_reference
     for key, got in (("k0", past.key_cache[0]), ("v0", past.value_cache[0]),
                      ("k_last", past.key_cache[last]), ("v_last", past.value_cache[last])):
         ref = g["cond_ctx." + key]
         assert got.shape == ref.shape
-        ma, cos = metrics(got, ref)
-        assert ma <= 0.03 * float(ref.float().abs().max()) and cos >= 0.999, (key, ma, cos)
+        exact = g.get("cond_ctx.exact." + key)
+        assert exact is not None, f"golden {name!r} holds no exact-arithmetic context: run tests/golden/add_exact_context.py"
+        check_tensor_vs_reference(got, ref, exact, name, "cond_ctx." + key)
 
 
 def test_prefill_with_existing_context_matches_checker():

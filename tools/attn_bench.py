@@ -31,18 +31,22 @@ def case(name, units, nv, ctx, Hq=28, Hkv=4, D=128, iters=10):
     variants = ["lib"]
     if os.environ.get("ATTN_FORMS"):   # also time the kernel's two forms explicitly
         variants += ["throughput", "latency"]
-    alt = os.environ.get("ATTN_AB_LIB")
-    if alt:
+    # ATTN_AB_LIBS=a.so,b.so (or ATTN_AB_LIB=one.so): other builds of the entry point, run round by round beside "lib"
+    alts = [a for a in (os.environ.get("ATTN_AB_LIBS") or os.environ.get("ATTN_AB_LIB") or "").split(",") if a]
+    alt_libs = {}
+    if alts:
         import ctypes
-        alt_lib = ctypes.CDLL(os.path.abspath(alt))
-        variants.append("alt")
+        for a in alts:
+            nm = os.path.basename(a).replace("libattn_", "").replace(".so", "")
+            alt_libs[nm] = ctypes.CDLL(os.path.abspath(a))
+            variants.append(nm)
 
     def run(v):
         if v in ("lib", "throughput", "latency"):
             K.lib().bagel_set_attn_deep({"lib": -1, "throughput": 0, "latency": 1}[v])
             K.varlen_attention(Q, Kw, Vt, O, t, len(tiles), Hq, Hkv, D, S)
         else:
-            rc = alt_lib.bagel_varlen_attention_bf16(K._p(Q), K._p(Kw), K._p(Vt), K._p(O), K._p(t), K.I(len(tiles)), K.I(Hq),
+            rc = alt_libs[v].bagel_varlen_attention_bf16(K._p(Q), K._p(Kw), K._p(Vt), K._p(O), K._p(t), K.I(len(tiles)), K.I(Hq),
                                                      K.I(Hkv), K.I(D), K.L(S), K._stream())
             assert rc == 0
 
@@ -66,7 +70,7 @@ def case(name, units, nv, ctx, Hq=28, Hkv=4, D=128, iters=10):
     for v in variants:
         ts = sorted(times[v])
         med = ts[len(ts) // 2]
-        print(f"{name:24s} {v} median {med:.3f} ms  {flops / med / 1e9:.0f} TFLOP/s  (min {ts[0]:.3f} ms)", flush=True)
+        print(f"{name:24s} {v:12s} median {med:.3f} ms  {flops / med / 1e9:.0f} TFLOP/s  (min {ts[0]:.3f} ms)", flush=True)
 
 
 if __name__ == "__main__":
