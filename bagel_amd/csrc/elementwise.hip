@@ -108,7 +108,7 @@ extern "C" int bagel_rmsnorm_bf16(const void* x, long ldx, void* out, long ldo, 
 // D/8 lanes per (row, head); lane j holds elements 8j..8j+7, its rotate_half partner is lane j ^ (D/16).
 // ---------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16* __restrict__ qkv, long ld, int M, int Hq,
+__device__ __forceinline__ void qk_norm_rope_block(int block, const bf16* __restrict__ qkv, long ld, int M, int Hq,
                                                            int Hkv, const bf16* __restrict__ qw_first,
                                                            const bf16* __restrict__ qw_second,
                                                            const bf16* __restrict__ kw_first,
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16* __restric
   // flight per lane the kernel is bound by (resident waves x bytes per wave) / memory latency, not by the memory system.
   constexpr int U = 2;
   const int NH = Hq + Hkv;
-  const long item = ((long)blockIdx.x * 256 + threadIdx.x) / LPH;
+  const long item = ((long)block * 256 + threadIdx.x) / LPH;
   const long pairs = (M + U - 1) / U;
   if (item >= pairs * NH) return;  // partial waves shuffle among live lanes only (a head's lanes leave together)
   const int j = threadIdx.x % LPH;
@@ -156,11 +156,10 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16* __restric
 // V rows of the fused qkv projection -> transposed value workspace Vt[kvh][d][slot] (2-byte stores,
 // consecutive lanes = consecutive token rows = consecutive slots, so a wave writes 128 contiguous bytes).
 template <int D>
-__global__ __launch_bounds__(256) void v_scatter_transposed_kernel(const bf16* __restrict__ qkv, long ld, int M,
-                                                                    int v_col0, int Hkv,
-                                                                    const int* __restrict__ row_slot,
-                                                                    bf16* __restrict__ Vt, long S) {
-  const int row = blockIdx.x * 64 + (threadIdx.x & 63);
+__device__ __forceinline__ void v_scatter_transposed_block(int block_x, int block_y, int grid_y, const bf16* __restrict__ qkv,
+                                                           long ld, int M, int v_col0, int Hkv,
+                                                           const int* __restrict__ row_slot, bf16* __restrict__ Vt, long S) {
+  const int row = block_x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;          // 4 waves split the Hkv*D/8 chunks
   if (row >= M) return;
   const long slot = row_slot[row];
@@ -168,12 +167,32 @@ __global__ __launch_bounds__(256) void v_scatter_transposed_kernel(const bf16* _
   const int nchunk = Hkv * D / 8;
   // gridDim.y workgroups share a 64-row block's chunks: 64 rows per workgroup alone are too few workgroups to fill the
   // chip at a few thousand rows (192 at 12288 rows)
-  for (int c = part + 4 * blockIdx.y; c < nchunk; c += 4 * gridDim.y) {
+  for (int c = part + 4 * block_y; c < nchunk; c += 4 * grid_y) {
     const bf16x8 v = *(const bf16x8*)(src + 8 * c);
     bf16* dst = Vt + (long)(8 * c) * S + slot;  // (kvh*D + d) * S with kvh*D + d == 8c + e
 #pragma unroll
     for (int e = 0; e < 8; ++e) dst[(long)e * S] = v[e];
   }
+}
+
+// One launch for both: the first v_blocks workgroups scatter the values (bound by their 2-byte store instructions),
+// the others normalise and rotate q / k (bound by memory latency); side by side each fills what the other leaves idle,
+// and the step pays one launch boundary instead of two.
+template <int D>
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16* __restrict__ qkv, long ld, int M, int Hq, int Hkv,
+                                                           const bf16* __restrict__ qw_first, const bf16* __restrict__ qw_second,
+                                                           const bf16* __restrict__ kw_first, const bf16* __restrict__ kw_second,
+                                                           int split, const bf16* __restrict__ cos_t, const bf16* __restrict__ sin_t,
+                                                           const int* __restrict__ row_cs, const int* __restrict__ row_slot,
+                                                           bf16* __restrict__ Q, bf16* __restrict__ Kws, long S, float eps,
+                                                           int und_rounding, bf16* __restrict__ Vt, int v_blocks, int v_split) {
+  const int b = blockIdx.x;   // uniform over the workgroup
+  if (b < v_blocks) {
+    v_scatter_transposed_block<D>(b / v_split, b % v_split, v_split, qkv, ld, M, (Hq + Hkv) * D, Hkv, row_slot, Vt, S);
+    return;
+  }
+  qk_norm_rope_block<D>(b - v_blocks, qkv, ld, M, Hq, Hkv, qw_first, qw_second, kw_first, kw_second, split, cos_t, sin_t, row_cs,
+                        row_slot, Q, Kws, S, eps, und_rounding);
 }
 
 extern "C" int bagel_qk_norm_rope_kv_bf16(const void* qkv, long ld, int M, int Hq, int Hkv, int head_dim,
@@ -191,22 +210,18 @@ extern "C" int bagel_qk_norm_rope_kv_bf16(const void* qkv, long ld, int M, int H
   hipStream_t st = (hipStream_t)stream;
   const int lph = head_dim / 8;
   const long threads = (long)((M + 1) / 2) * (Hq + Hkv) * lph;   // two token rows per thread
-  const dim3 grid((threads + 255) / 256), block(256);
+  const int qk_blocks = (int)((threads + 255) / 256);
   // value scatter: up to 8 workgroups per 64-row block while that still leaves each wave a chunk (Hkv * D / 8 chunks, 4 waves)
   int v_split = 1;
   while (v_split < 8 && (long)((M + 63) / 64) * v_split < 4L * bagel_cu_count() && Hkv * head_dim / 8 >= 8 * v_split) v_split *= 2;
+  const int v_blocks = (M + 63) / 64 * v_split;
+  const dim3 grid(v_blocks + qk_blocks), block(256);
 #define ARGS (const bf16*)qkv, ld, M, Hq, Hkv, (const bf16*)q_norm_first, (const bf16*)q_norm_second,                \
              (const bf16*)k_norm_first, (const bf16*)k_norm_second, split_row, (const bf16*)cos_table,               \
-             (const bf16*)sin_table, (const int*)row_cs, (const int*)row_slot, (bf16*)Q, (bf16*)K_ws, S, eps, und_rounding
-  if (head_dim == 128) {
-    hipLaunchKernelGGL(qk_norm_rope_kernel<128>, grid, block, 0, st, ARGS);
-    hipLaunchKernelGGL(v_scatter_transposed_kernel<128>, dim3((M + 63) / 64, v_split), block, 0, st, (const bf16*)qkv, ld, M,
-                       (Hq + Hkv) * head_dim, Hkv, (const int*)row_slot, (bf16*)Vt_ws, S);
-  } else {
-    hipLaunchKernelGGL(qk_norm_rope_kernel<64>, grid, block, 0, st, ARGS);
-    hipLaunchKernelGGL(v_scatter_transposed_kernel<64>, dim3((M + 63) / 64, v_split), block, 0, st, (const bf16*)qkv, ld, M,
-                       (Hq + Hkv) * head_dim, Hkv, (const int*)row_slot, (bf16*)Vt_ws, S);
-  }
+             (const bf16*)sin_table, (const int*)row_cs, (const int*)row_slot, (bf16*)Q, (bf16*)K_ws, S, eps, und_rounding, \
+             (bf16*)Vt_ws, v_blocks, v_split
+  if (head_dim == 128) hipLaunchKernelGGL(qk_norm_rope_kernel<128>, grid, block, 0, st, ARGS);
+  else hipLaunchKernelGGL(qk_norm_rope_kernel<64>, grid, block, 0, st, ARGS);
 #undef ARGS
   BAGEL_LAUNCH_CHECK();
   return 0;

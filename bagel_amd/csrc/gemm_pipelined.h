@@ -48,9 +48,10 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
   const int piece_row = lane >> 3;
   const int src_chunk = (lane & 7) ^ piece_row;
   int m0, n0;
-  // ---- even split (LEAD false): every wave stages an eighth of each tile
-  const bf16* a_src[4];
-  const bf16* w_src[W_ITERS];
+  // ---- even split (LEAD false): every wave stages an eighth of each tile.  A piece's address is a scalar base (the
+  // operand + the K step's offset, both uniform) + one 32-bit lane offset that is fixed for the tile, so the pieces
+  // of a tile cost one register each and the K step's advance is scalar arithmetic.
+  unsigned a_src[4], w_src[W_ITERS];
   auto set_tile_even = [&](int t) {
     int tile_m, tile_n;
     gemm_tile_of_block(p, t, tile_m, tile_n);
@@ -64,26 +65,28 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = (it * NW + wave) * 8 + piece_row;
-      a_src[it] = p.A + (long)min(lm0 + row, p.M - 1) * p.lda + src_chunk * 8;
+      a_src[it] = (unsigned)(((long)min(lm0 + row, p.M - 1) * p.lda + src_chunk * 8) * 2);
     }
 #pragma unroll
     for (int it = 0; it < W_ITERS; ++it) {
       const int row = (it * NW + wave) * 8 + piece_row;
-      w_src[it] = p.W + (long)min(ln0 + row, p.N - 1) * p.ldw + src_chunk * 8;
+      w_src[it] = (unsigned)(((long)min(ln0 + row, p.N - 1) * p.ldw + src_chunk * 8) * 2);
     }
   };
   auto stage_a_even = [&](int kt) {
     char* base = smem + (kt & 1) * STAGE_BYTES;
+    const char* src = (const char*)p.A + kt * (BK * 2);
 #pragma unroll
     for (int it = 0; it < 4; ++it)
-      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a_src[it] + kt * BK), LDS_PTR(base + (it * NW + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + a_src[it]), LDS_PTR(base + (it * NW + wave) * 1024), 16, 0, 0);
   };
   auto stage_w_even = [&](int kt) {
     char* base = smem + (kt & 1) * STAGE_BYTES + A_BYTES;
+    const char* src = (const char*)p.W + kt * (BK * 2);
 #pragma unroll
     for (int it = 0; it < W_ITERS; ++it)
       if (W_EVEN || it + 1 < W_ITERS || it * NW + wave < W_PIECES)  // wave-uniform
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(w_src[it] + kt * BK), LDS_PTR(base + (it * NW + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + w_src[it]), LDS_PTR(base + (it * NW + wave) * 1024), 16, 0, 0);
   };
 
   // ---- leading-wave split (LEAD true)
