@@ -251,34 +251,52 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmParams p)
     w_src[it] = p.W + (long)grow * p.ldw + src_chunk * 8;
   }
 
+  // A_CONV3X3: K runs over (tap, channel).  The tap and the per-piece source (bounds test, pixel address) change only
+  // every Cin / 64 K steps, and stage() is called with consecutive kt, so they are carried from call to call and
+  // re-derived only when the channel offset wraps (for Cin = 512 once in eight K steps).
+  int conv_c0 = 0, conv_tap = -1;
+  const bf16* conv_src[A_ITERS];
+  auto conv_set_tap = [&](int tap) {
+    conv_tap = tap;
+    const int tap_dy = tap / 3 - 1, tap_dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) {
+      int y = a_oy[it] + tap_dy, x = a_ox[it] + tap_dx;
+      bool ok = y >= 0 && y < p.Hout && x >= 0 && x < p.Wout;
+      if (p.upsample == 1) {
+        y >>= 1;
+        x >>= 1;
+      } else if (p.upsample == 2) {
+        y = 2 * a_oy[it] + tap_dy + 1;
+        x = 2 * a_ox[it] + tap_dx + 1;
+        ok = y < p.Hin && x < p.Win;
+      }
+      // out-of-image taps read the zero page at every channel offset: its pointer is biased so that + c0 stays on it
+      conv_src[it] = ok ? a_src[it] + ((long)y * p.Win + x) * p.Cin : nullptr;
+    }
+  };
+
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * STAGE_BYTES;
     const int koff = kt * BK;
-    int tap_dy = 0, tap_dx = 0, c0 = 0;
     if constexpr (AMODE == A_CONV3X3) {
-      const int tap = koff / p.Cin;
-      c0 = koff - tap * p.Cin;
-      tap_dy = tap / 3 - 1;
-      tap_dx = tap - (tap / 3) * 3 - 1;
+      if (conv_tap < 0) {            // first call: wherever the K range starts
+        const int tap = koff / p.Cin;
+        conv_c0 = koff - tap * p.Cin;
+        conv_set_tap(tap);
+      } else {
+        conv_c0 += BK;
+        if (conv_c0 >= p.Cin) {
+          conv_c0 = 0;
+          conv_set_tap(conv_tap + 1);
+        }
+      }
     }
 #pragma unroll
     for (int it = 0; it < A_ITERS; ++it) {
       const bf16* src;
-      if constexpr (AMODE == A_DENSE) {
-        src = a_src[it] + koff;
-      } else {
-        int y = a_oy[it] + tap_dy, x = a_ox[it] + tap_dx;
-        bool ok = y >= 0 && y < p.Hout && x >= 0 && x < p.Wout;
-        if (p.upsample == 1) {
-          y >>= 1;
-          x >>= 1;
-        } else if (p.upsample == 2) {
-          y = 2 * a_oy[it] + tap_dy + 1;
-          x = 2 * a_ox[it] + tap_dx + 1;
-          ok = y < p.Hin && x < p.Win;
-        }
-        src = ok ? a_src[it] + ((long)y * p.Win + x) * p.Cin + c0 : p.zeros + src_chunk * 8;
-      }
+      if constexpr (AMODE == A_DENSE) src = a_src[it] + koff;
+      else src = conv_src[it] != nullptr ? conv_src[it] + conv_c0 : p.zeros + src_chunk * 8;
       __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(base + (it * NW + wave) * 1024), 16, 0, 0);
     }
 #pragma unroll

@@ -39,16 +39,27 @@ extern "C" int bagel_conv3x3_nhwc_bf16(const void* x, int Hin, int Win, int Cin,
   p.alpha = 1.f;
   p.zeros = (const bf16*)zero_page;
   p.diag = nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  if (Cout <= 32 && !residual) {
+    // conv_out (three output channels): a 128-wide tile would spend its whole width on padding, the pass over the
+    // input is what costs: 128 x 32 tiles, one wave per 32 rows
+    constexpr int BM = 128, BN = 32;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = 1;
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, 4, 1, EPI_BIAS, A_CONV3X3>), dim3(p.tiles_m), dim3(256),
+                       2 * (BM + BN) * ROW_BYTES, st, p);
+    BAGEL_LAUNCH_CHECK();
+    return 0;
+  }
   constexpr int BM = 128, BN = 128;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   const size_t lds = 2 * (BM + BN) * ROW_BYTES;
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
   if (residual)
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, 2, 2, EPI_BIAS_RESIDUAL, A_CONV3X3>), grid, block, lds,
-                       (hipStream_t)stream, p);
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, 2, 2, EPI_BIAS_RESIDUAL, A_CONV3X3>), grid, block, lds, st, p);
   else
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, 2, 2, EPI_BIAS, A_CONV3X3>), grid, block, lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, 2, 2, EPI_BIAS, A_CONV3X3>), grid, block, lds, st, p);
   BAGEL_LAUNCH_CHECK();
   return 0;
 }
@@ -227,14 +238,29 @@ extern "C" int bagel_groupnorm_swish_nhwc_bf16(const void* x, long npix, int C, 
 // scaled epilogue (S = Q.K^T / sqrt(C)) and a second GEMM (P.V) this is AttnBlock.attention
 // (autoencoder.py:50-62): single head, head dim = 512 channels, all H*W tokens.
 // -------------------------------------------------------------------------------------------------
+// Rows of up to 256 x 4 x ROW_REGS values are read ONCE and kept in registers between the three passes (maximum, sum,
+// normalise): 16384 keys are 64 values per thread.  Longer rows take the re-reading form.
+constexpr int SOFTMAX_ROW_REGS = 16;   // f32x4 per thread
+template <bool IN_REGS>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, long lds_, int n,
                                                            bf16* __restrict__ p, long ldp) {
   const float* row = s + (long)blockIdx.x * lds_;
   __shared__ float sh[8];
+  f32x4 keep[IN_REGS ? SOFTMAX_ROW_REGS : 1];
   float m = -INFINITY;
-  for (int i = threadIdx.x * 4; i < n; i += 1024) {
-    const f32x4 v = *(const f32x4*)(row + i);
-    m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  if constexpr (IN_REGS) {
+#pragma unroll
+    for (int r = 0; r < SOFTMAX_ROW_REGS; ++r) {
+      const int i = threadIdx.x * 4 + r * 1024;
+      keep[r] = i < n ? *(const f32x4*)(row + i) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    }
+#pragma unroll
+    for (int r = 0; r < SOFTMAX_ROW_REGS; ++r) m = fmaxf(fmaxf(m, fmaxf(keep[r][0], keep[r][1])), fmaxf(keep[r][2], keep[r][3]));
+  } else {
+    for (int i = threadIdx.x * 4; i < n; i += 1024) {
+      const f32x4 v = *(const f32x4*)(row + i);
+      m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -242,23 +268,47 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   __syncthreads();
   m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
   __syncthreads();
+  // the same order of additions in both forms: a thread's values in index order, then the wave, then the four waves
   float sum = 0.f;
-  for (int i = threadIdx.x * 4; i < n; i += 1024) {
-    const f32x4 v = *(const f32x4*)(row + i);
+  if constexpr (IN_REGS) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) sum += __expf(v[e] - m);
+    for (int r = 0; r < SOFTMAX_ROW_REGS; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        keep[r][e] = __expf(keep[r][e] - m);      // exp(-inf) = 0 for the slots past the row's end
+        sum += keep[r][e];
+      }
+  } else {
+    for (int i = threadIdx.x * 4; i < n; i += 1024) {
+      const f32x4 v = *(const f32x4*)(row + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum += __expf(v[e] - m);
+    }
   }
   sum = wave_sum(sum);
   if ((threadIdx.x & 63) == 0) sh[4 + (threadIdx.x >> 6)] = sum;
   __syncthreads();
   const float inv = 1.0f / (sh[4] + sh[5] + sh[6] + sh[7]);
   bf16* prow = p + (long)blockIdx.x * ldp;
-  for (int i = threadIdx.x * 4; i < n; i += 1024) {
-    const f32x4 v = *(const f32x4*)(row + i);
-    bf16x4 o;
+  if constexpr (IN_REGS) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (bf16)(__expf(v[e] - m) * inv);
-    *(bf16x4*)(prow + i) = o;
+    for (int r = 0; r < SOFTMAX_ROW_REGS; ++r) {
+      const int i = threadIdx.x * 4 + r * 1024;
+      if (i < n) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)(keep[r][e] * inv);
+        *(bf16x4*)(prow + i) = o;
+      }
+    }
+  } else {
+    for (int i = threadIdx.x * 4; i < n; i += 1024) {
+      const f32x4 v = *(const f32x4*)(row + i);
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)(__expf(v[e] - m) * inv);
+      *(bf16x4*)(prow + i) = o;
+    }
   }
 }
 
@@ -266,8 +316,12 @@ extern "C" int bagel_softmax_rows_f32_bf16(const void* scores, long lds_, int ro
                                            void* stream) {
   BAGEL_CHECK(scores && probs && rows > 0 && n > 0 && n % 4 == 0 && lds_ % 4 == 0 && ldp % 4 == 0,
               "bagel_softmax_rows_f32_bf16: bad arguments");
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const float*)scores, lds_, n,
-                     (bf16*)probs, ldp);
+  if (n <= 1024 * SOFTMAX_ROW_REGS)
+    hipLaunchKernelGGL(softmax_rows_kernel<true>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const float*)scores, lds_, n,
+                       (bf16*)probs, ldp);
+  else
+    hipLaunchKernelGGL(softmax_rows_kernel<false>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const float*)scores, lds_, n,
+                       (bf16*)probs, ldp);
   BAGEL_LAUNCH_CHECK();
   return 0;
 }

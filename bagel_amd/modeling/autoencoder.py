@@ -58,8 +58,10 @@ class AutoEncoder:
                 self.w[name] = t.to(dev)                         # GroupNorm affine, fp32
         self.zero_page = torch.zeros(256, dtype=torch.uint8, device=dev)
         self._buf: Dict[str, torch.Tensor] = {}
-        # query rows of the mid-block attention whose fp32 scores are held at once (16384 keys x 4096 rows = 256 MiB)
-        self.score_chunk = 4096
+        # query rows of the mid-block attention whose fp32 scores are held at once: all 16384 of a 1024 x 1024 image
+        # (1 GiB of scores + 0.5 GiB of probabilities) - the P.V product then has 512 output tiles, two per CU,
+        # where a 4096-row chunk left half the chip idle; results do not depend on the chunk
+        self.score_chunk = 16384
 
     def eval(self):
         return self
