@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from tests.helpers import OracleRun, scenario_state_dict  # noqa: E402
-from tests.scenarios import SCENARIOS  # noqa: E402
+from tests.scenarios import SCENARIOS, IMAGE_CTX_CASES  # noqa: E402
 
 
 def exact_context_tensors(sc, sd=None, lazy=False):
@@ -30,10 +30,31 @@ def exact_context_tensors(sc, sd=None, lazy=False):
             "cond_ctx.exact.v_last": pk.value_cache[last].float().clone()}
 
 
+def upgrade_image_ctx(name):
+    from tests.test_oracle_image_ctx import exact_twins
+    path = os.path.join(HERE, name + ".safetensors")
+    with safe_open(path, framework="pt") as f:
+        tensors = {k: f.get_tensor(k) for k in f.keys()}
+        meta = f.metadata()
+    if any(k.startswith("exact.") for k in tensors):
+        return
+    with torch.no_grad():
+        twins = exact_twins(IMAGE_CTX_CASES[name], tensors)
+    for k, v in twins.items():
+        assert v.shape == tensors[k[len("exact."):]].shape, k
+    tensors.update(twins)
+    save_file({k: v.contiguous() for k, v in tensors.items()}, path, metadata=meta)
+    worst = max(float((tensors[k[len("exact."):]].float() - v).abs().max()) for k, v in twins.items())
+    print(f"[{name}] added {len(twins)} exact tensors; largest reference-vs-exact distance {worst:.4f}", flush=True)
+
+
 if __name__ == "__main__":
-    for name in sys.argv[1:] or list(SCENARIOS):
+    for name in sys.argv[1:] or list(SCENARIOS) + list(IMAGE_CTX_CASES):
         path = os.path.join(HERE, name + ".safetensors")
         if not os.path.exists(path):
+            continue
+        if name in IMAGE_CTX_CASES:
+            upgrade_image_ctx(name)
             continue
         with safe_open(path, framework="pt") as f:
             tensors = {k: f.get_tensor(k) for k in f.keys()}

@@ -312,6 +312,9 @@ def run_image_ctx_case(ic):
             for i, rec in enumerate(steps):
                 for k, v in rec.items():
                     out[f"edit.step{i}.{k}"] = v
+    # exact-arithmetic twins (fp32, no rounding points) of every float tensor, from the CPU checker
+    from test_oracle_image_ctx import exact_twins
+    out.update(exact_twins(ic, out))
     save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, f"{ic.name}.safetensors"),
               metadata={"source": "reference Bagel image-context prefill (+ edit generation) on CPU, bf16 weights + bf16 "
                                   "autocast, fp32 VAE, SDPA stand-in for flash_attn, identity image transforms"})

@@ -11,13 +11,23 @@ from bagel_amd.weights import (make_llm_state_dict, make_vit_state_dict, make_va
                                make_vae_decoder_state_dict)
 
 
-def run_oracle_case(ic, g):
-    """Mirror of tests/golden/make_golden.py:run_image_ctx_case on the checker."""
+def run_oracle_case(ic, g, exact=False):
+    """Mirror of tests/golden/make_golden.py:run_image_ctx_case on the checker.  ``exact``: the same graph in fp32 with
+    no bf16 rounding point (the exact-arithmetic answer the parity bounds are relative to)."""
+    if exact:
+        with O.exact_arithmetic():
+            return _run_oracle_case(ic, g, True)
+    return _run_oracle_case(ic, g, False)
+
+
+def _run_oracle_case(ic, g, exact):
     dims = ic.dims
     sd = make_llm_state_dict(dims, seed=ic.weight_seed)
     sd.update(make_vit_state_dict(dims, seed=ic.weight_seed))
     vsd = make_vae_encoder_state_dict(dims.vae, seed=0)
     vsd.update(make_vae_decoder_state_dict(dims.vae, seed=0))
+    if exact:
+        sd = {k: v.float() for k, v in sd.items()}
     n, L = ic.batch, dims.num_layers
     out = {}
 
@@ -58,6 +68,22 @@ def run_oracle_case(ic, g):
             out["edit.contexts"] = dict(cond=(past, kvlens, ropes), text=text_ctx, img=(img_past, ikv, irope))
             out["edit.inputs"] = (gg, gt, gm)
     return sd, vsd, out
+
+
+def exact_twins(ic, g):
+    """``exact.<name>`` for every float tensor of an image-context golden that the checker also produces, and the
+    exact-arithmetic branch velocities of the editing steps (teacher-forced from the golden's x_t)."""
+    sd, vsd, out = run_oracle_case(ic, g, exact=True)
+    twins = {f"exact.{k}": v.float().clone() for k, v in out.items()
+             if isinstance(v, torch.Tensor) and v.is_floating_point() and k in g and k != "edit.init_noise"}
+    if ic.edit_prompt is not None:
+        ts, _ = O.flow_timesteps(ic.num_timesteps, 3.0)
+        for i in range(ic.num_timesteps - 1):
+            with torch.no_grad(), O.exact_arithmetic():
+                vt, (vc, vx, vm) = edit_flow(ic, sd, out, g[f"edit.step{i}.x_t"].float(), ts[i])
+            for k, v in (("v_cond", vc), ("v_text", vx), ("v_img", vm), ("v_t", vt)):
+                twins[f"exact.edit.step{i}.{k}"] = v.float().clone()
+    return twins
 
 
 def edit_flow(ic, sd, out, x_t, t):
