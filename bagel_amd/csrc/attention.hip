@@ -29,9 +29,6 @@
 #ifndef ATTN_QK_RING
 #define ATTN_QK_RING 3      // key fragments in flight ahead of the score products
 #endif
-#ifndef ATTN_PIN
-#define ATTN_PIN 2          // 1: pin the product / read alternation with sched_group_barrier
-#endif
 
 struct AttnTile {
   int q_row0;       // first query row (row index into Q / O)
@@ -218,9 +215,7 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 3) void attention_kernel(AttnParams
     };
 #pragma unroll
     for (int i = 0; i < RING; ++i) kf[i] = kread(i);
-#if ATTN_PIN == 2
     __builtin_amdgcn_sched_barrier(0);
-#endif
     if constexpr (DEEP) {
       if (kt + 1 < n_kt) {
         stage_k(kt + 1, (kt + 1) & 1);
@@ -238,23 +233,10 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 3) void attention_kernel(AttnParams
       // the values' DMA pieces go out one by one between the products (LDS reads and LDS-DMA keep program order)
       if constexpr (!DEEP)
         if (i % 2 == 1 && i / 2 < V_IT) stage_v_piece(kt, 0, i / 2);
-#if ATTN_PIN == 2
       // The scheduler, left alone, sinks every read to just before its product to save registers, and each product
       // then waits out a whole LDS round trip: nothing may cross from one product / piece / read group to the next.
       __builtin_amdgcn_sched_barrier(0);
-#endif
     }
-#if ATTN_PIN == 1
-    // The order above, told to the scheduler (left alone it sinks every read to just before its product to save
-    // registers, and each product then waits out a whole LDS round trip): RING reads, then product, [DMA piece], read.
-    __builtin_amdgcn_sched_group_barrier(0x100, RING, 0);
-#pragma unroll
-    for (int i = 0; i < 2 * KS; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (!DEEP && i % 2 == 1 && i / 2 < V_IT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      if (i + RING < 2 * KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-#endif
     // mask the tail keys of the last tile (raw scores; the softmax scale is folded into the exponent)
     const int key0 = kt * KT;
     const bool tail = key0 + KT > (causal ? t.causal_base + wave * 32 + 1 : kv_len);  // wave-uniform

@@ -35,7 +35,14 @@ def main(root, out_path, command=""):
         if key in sq:
             c = sq[key]["counters_per_launch"]
             cycles = c["GRBM_GUI_ACTIVE"] / XCDS
-            row["clock_ghz_held"] = cycles / (sq[key]["avg_duration_us"] * 1e3)
+            clock = cycles / (sq[key]["avg_duration_us"] * 1e3)
+            # GRBM_GUI_ACTIVE / duration reads high on launches shorter than about 0.3 ms (2.6 - 3.8 "GHz" on a
+            # 2.4 GHz part): below that the quotient is kept under another name and the busy fraction, which divides
+            # by the same cycle count, is flagged with it
+            if sq[key]["avg_duration_us"] >= 300.0:
+                row["clock_ghz_held"] = clock
+            else:
+                row["clock_quotient_unreliable_short_launch"] = clock
             row["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (CUS * SIMDS * cycles)
             for name in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
                 if name in c and c.get("SQ_WAVE_CYCLES"):
