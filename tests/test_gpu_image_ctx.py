@@ -82,6 +82,8 @@ def test_random_image_contexts_match_cpu_checker():
             _check_case(ic, g, ic.name)
         except AssertionError as e:
             raise AssertionError(f"case {case}: prompts {first} vae {vae_images} vit {vit_images} L={ic.dims.num_layers}: {e}")
+        if case % 10 == 9:
+            print(f"  image-context case {case + 1} of {n_cases} ok", flush=True)     # a long soak stays audible under -s
     print(f"{n_cases} random image contexts agree with the CPU checker")
 
 
