@@ -150,13 +150,14 @@ class MoTWeights:
 
 
 @dataclass
-class TaylorStep:
-    """What forward_gen does with the TaylorSeer cache in one step."""
-    kind: str                   # "full": update the cache after the layers; "Taylor": skip the layers
-    factors: torch.Tensor       # [7, rows * H] bf16, rows = latent rows of the step's plan (a prefix of the full plan's)
-    n_factors: int              # full: factors the cache holds after this update; Taylor: factors to sum
-    distance: int = 1           # full: steps since the previous full step
-    x: int = 0                  # Taylor: steps since the last full step
+class TaylorUpdate:
+    """One CFG branch's TaylorSeer cache update after a full forward: the branch's latent rows of the plan that ran
+    (``row0`` .. ``row0 + rows``) feed its factor cache."""
+    row0: int
+    rows: int
+    factors: torch.Tensor       # [7, rows * H] bf16 view (row stride = the whole cache's), this branch's rows
+    n_factors: int              # factors the cache holds after this update
+    distance: int = 1           # steps (of this branch) since its previous full step
 
 
 class TaylorSchedule:
@@ -267,20 +268,25 @@ class MoTEngine:
         return cur[:n].view(*shape)
 
     # ---- planning -------------------------------------------------------------------------
-    def build_plan(self, units: List[GenUnit], sample_nv: Sequence[int], sample_row0: Sequence[int]) -> GenPlan:
+    def build_plan(self, units: List[GenUnit], sample_nv: Sequence[int], sample_row0: Sequence[int],
+                   kv_start: Optional[Sequence[int]] = None, S: Optional[int] = None) -> GenPlan:
         """Row layout: latent rows of unit 0, unit 1, ... then two text rows per unit.
-        ``sample_row0[b]`` is the first row of sample b in the packed latent x_t."""
+        ``sample_row0[b]`` is the first row of sample b in the packed latent x_t.  ``kv_start`` / ``S``: the units' key
+        slots inside a workspace laid out by another plan (a plan over a subset of that plan's units)."""
         d = self.dims
         nv = [sample_nv[u.sample] for u in units]
         Mv, Mt = sum(nv), 2 * len(units)
-        kv_start, vae_row0 = [], []
+        own_slots = kv_start is None
+        kv_start = [] if own_slots else list(kv_start)
+        vae_row0 = []
         s = r = 0
         for u, n in zip(units, nv):
-            kv_start.append(s)
+            if own_slots:
+                kv_start.append(s)
             vae_row0.append(r)
             s += (u.ctx_len + n + 2 + 63) // 64 * 64
             r += n
-        S = s
+        S = s if S is None else S
         row_cs = torch.empty(Mv + Mt, dtype=torch.int32)
         row_slot = torch.empty(Mv + Mt, dtype=torch.int32)
         src_row = torch.empty(Mv, dtype=torch.int32)
@@ -332,16 +338,28 @@ class MoTEngine:
                 self.vtws[l, :, :, ks:ks + u.ctx_len].copy_(u.ctx_v[l].permute(1, 2, 0))
 
     # ---- the forward ----------------------------------------------------------------------
+    def taylor_velocity(self, factors: torch.Tensor, rows: int, n_factors: int, x: int) -> torch.Tensor:
+        """A CFG branch's velocities on one of its skipped ("Taylor") steps: the Taylor expansion of its cached
+        last-layer output (every layer of the reference returns its own expansion and ignores its input,
+        qwen2_navit.py:838-843, so only the last layer's reaches the head), then final norm + llm2vae.  No embedding,
+        no layers, no KV."""
+        d, w = self.dims, self.w
+        X = self._get("tX", (rows, d.hidden_size))
+        Xn = self._get("tXn", (rows, d.hidden_size))
+        V = self._get("tV", (rows, d.patch_latent_dim))
+        K.taylor_eval(factors, rows, d.hidden_size, n_factors, x, X)
+        K.rmsnorm(X, Xn, w.norm[0], w.norm[1], rows, d.rms_norm_eps, rows=rows)
+        K.gemm(Xn, w.l2v_w, V, bias=w.l2v_b, M=rows)
+        return V
+
     def forward_gen(self, plan: GenPlan, x_bf16: torch.Tensor, temb: torch.Tensor, text_emb: torch.Tensor,
-                    taylor: Optional["TaylorStep"] = None):
+                    taylor_updates: Optional[List["TaylorUpdate"]] = None):
         """x_bf16 [rows of the packed latent, P], temb [H], text_emb [Mt, H] -> velocities [Mv, P] (bf16),
         rows in unit order.  Mirrors Bagel._forward_flow's embedding + forward_inference(mode="gen") +
         llm2vae for all units at once (bagel.py:1389-1426, qwen2_navit.py:1041-1115).
 
-        ``taylor`` (TaylorSeer, qwen2_navit.py:838-843): on a "full" step the last layer's output of the latent
-        rows updates the factor cache; on a "Taylor" step the whole stack is skipped and that output is the
-        Taylor expansion of the cache (every layer of the reference returns its own expansion and ignores its
-        input, so only the last layer's reaches the head)."""
+        ``taylor_updates`` (TaylorSeer): after the layers, the last layer's output of each listed row range updates
+        that CFG branch's factor cache (derivative_approximation, modeling/cache_utils/taylorseer.py:11-29)."""
         d, w = self.dims, self.w
         H, I, Hq, Hkv, D = d.hidden_size, d.intermediate_size, d.num_heads, d.num_kv_heads, d.head_dim
         Mv, Mt, M = plan.Mv, plan.Mt, plan.M
@@ -357,12 +375,6 @@ class MoTEngine:
         skw = self._get("skinny_ws", (16 * 64 * max(2 * I, qkv_dim),), dtype=torch.float32)
         eps = d.rms_norm_eps
 
-        if taylor is not None and taylor.kind == "Taylor":
-            K.taylor_eval(taylor.factors, Mv, H, taylor.n_factors, taylor.x, X)
-            K.rmsnorm(X, Xn, w.norm[0], w.norm[1], Mv, eps, rows=Mv)
-            K.gemm(Xn, w.l2v_w, Vout, bias=w.l2v_b, M=Mv)
-            return Vout
-
         # embedding: vae2llm(x_t) + t_emb + pos_embed on latent rows, embed_tokens on text rows
         K.gemm(x_bf16, w.v2l_w, lin, bias=w.v2l_b)
         K.embed_latent(lin, temb, w.pos_embed, self._pos_id, plan.src_row, X, Mv)
@@ -375,8 +387,8 @@ class MoTEngine:
         K.mot_forward(self._cdims, w.layer_table(), len(w.layers), rows, self.kws, self.vtws, final_norm_gen=w.norm[0],
                       final_norm_und=w.norm[1], final_norm_rows=Mv)
 
-        if taylor is not None:
-            K.taylor_update(X[:Mv], taylor.factors, taylor.n_factors, taylor.distance)
+        for tu in taylor_updates or ():
+            K.taylor_update(X[tu.row0:tu.row0 + tu.rows], tu.factors, tu.n_factors, tu.distance)
         K.gemm(Xn, w.l2v_w, Vout, bias=w.l2v_b, M=Mv)
         return Vout
 

@@ -14,7 +14,7 @@ import torch
 from .. import _lib as K
 from .. import packing
 from ..config import BagelDims
-from ..engine import GenUnit, MoTEngine, MoTWeights, TaylorSchedule, TaylorStep
+from ..engine import GenUnit, MoTEngine, MoTWeights, TaylorSchedule, TaylorUpdate
 from ..parallel import exchange_velocities, plan_exchange, world_info
 
 BF16 = torch.bfloat16
@@ -405,9 +405,11 @@ class Bagel:
         dedup_identical_branches: bool = False,
     ):
         """Bagel.generate_image (bagel.py:1237-1347).  Returns a tuple of per-image ``[Nv, 64]`` fp32 latents
-        (on the device).  ``enable_taylorseer`` skips two of three forwards after the first five steps and
-        extrapolates the last layer's output instead (modeling/cache_utils/taylorseer.py); it is offered when all
-        CFG branches start at step 0, so that their schedules coincide and the packed forward stays one launch.
+        (on the device).  ``enable_taylorseer`` skips two of three forwards after a branch's first five and
+        extrapolates the last layer's output instead (modeling/cache_utils/taylorseer.py).  Every CFG branch keeps its
+        own schedule and factor cache as in the reference (bagel.py:1273-1277): a branch that first runs after step 0
+        (a CFG interval that opens late) counts its own steps, so in one Euler step some branches may run the layers
+        while others are extrapolated; the branches that run are packed into one forward.
         When torch.distributed is initialised with more than one rank, the (sample, branch) units of each
         step are split over the ranks of ``group`` (bagel_amd/parallel.py); every rank must make the same call
         and every rank returns the same latents.
@@ -440,6 +442,11 @@ class Bagel:
                                            cfg_img_past_key_values, cpu(cfg_img_key_values_lens),
                                            cpu(cfg_img_packed_key_value_indexes))
             img_is_cond = dedup_identical_branches and all(self._same_unit(a, b) for a, b in zip(units[:n_cond], img_units))
+            if img_is_cond and enable_taylorseer:
+                # the image-free branch keeps its own TaylorSeer schedule, which only coincides with the conditional
+                # one while both have run in every step so far: the CFG interval must open at the first step
+                t0 = float(timestep_shift / (1 + (timestep_shift - 1)))      # the first timestep (1 after the shift)
+                img_is_cond = cfg_interval[0] < t0 <= cfg_interval[1]
             if not img_is_cond:
                 units += img_units
 
@@ -462,13 +469,6 @@ class Bagel:
         # text rows: embed_tokens([soi, eoi]) per unit, constant over steps (bagel.py:1389-1391)
         ids = cpu(packed_text_ids).to(torch.int32)
         text_emb = {}
-        for plan in (plan_full, plan_cond):
-            if plan is None:
-                continue
-            idx = torch.cat([ids[2 * u.sample:2 * u.sample + 2] for u in plan.units]).to(dev)
-            te = torch.empty((plan.Mt, d.hidden_size), device=dev, dtype=BF16)
-            K.gather_rows(eng.w.embed_tokens, idx, te, plan.Mt)
-            text_emb[id(plan)] = te
 
         # timesteps exactly as the reference builds them, in fp32 on the host (bagel.py:1286-1289)
         timesteps = torch.linspace(1, 0, num_timesteps)
@@ -483,13 +483,48 @@ class Bagel:
         v_t = torch.empty((Nv, d.patch_latent_dim), device=dev, dtype=BF16)
         cfg_ws = torch.empty(K.cfg_workspace_bytes(Nv, d.patch_latent_dim), device=dev, dtype=torch.uint8)
 
-        # TaylorSeer: one schedule per CFG branch as in the reference (bagel.py:1273-1277); the factor cache covers
-        # the latent rows of the full plan, whose first rows are the cond plan's
+        # text rows of a plan over a subset of the full plan's units
+        def text_rows(plan):
+            if id(plan) not in text_emb:
+                idx = torch.cat([ids[2 * u.sample:2 * u.sample + 2] for u in plan.units]).to(dev)
+                te = torch.empty((plan.Mt, d.hidden_size), device=dev, dtype=BF16)
+                K.gather_rows(eng.w.embed_tokens, idx, te, plan.Mt)
+                text_emb[id(plan)] = te
+            return text_emb[id(plan)]
+
+        # TaylorSeer: one schedule and one factor cache per CFG branch as in the reference (bagel.py:1273-1277).  The
+        # caches are the row ranges of the branches' latent rows inside the local full plan.
         schedules = factors = None
+        branch_rows, sub_plans = {}, {}
         if enable_taylorseer:
             schedules = {b: TaylorSchedule() for b in (0, 1, 2)}
-            rows_max = max(p_.Mv for p_ in (plan_full, plan_cond) if p_ is not None) if (plan_full or plan_cond) else 0
-            factors = torch.empty((7, max(rows_max, 1) * d.hidden_size), device=dev, dtype=BF16)
+            base = plan_full if plan_full is not None else plan_cond
+            if base is not None:
+                for u, r0, n in zip(base.units, base.vae_row0, base.nv):
+                    a, cnt = branch_rows.get(u.branch, (r0, 0))
+                    branch_rows[u.branch] = (a, cnt + n)           # a branch's units are adjacent (branch-major order)
+                factors = torch.empty((7, base.Mv * d.hidden_size), device=dev, dtype=BF16)
+
+        def rows_of(plan, branch):
+            """(first latent row, rows) of a branch inside ``plan``."""
+            r0 = cnt = None
+            for u, a, n in zip(plan.units, plan.vae_row0, plan.nv):
+                if u.branch == branch:
+                    r0, cnt = (a, n) if r0 is None else (r0, cnt + n)
+            return r0, cnt
+
+        def plan_for(branches, step_plan):
+            """The step's plan restricted to the given branches: same key slots (the workspace is laid out once, by the
+            full plan), latent rows compacted."""
+            if set(branches) == {u.branch for u in step_plan.units}:
+                return step_plan
+            key = tuple(branches)
+            if key not in sub_plans:
+                slot = {(u.sample, u.branch): ks for u, ks in zip(plan_full.units, plan_full.kv_start)}
+                us = [u for u in plan_full.units if u.branch in branches]
+                sub_plans[key] = eng.build_plan(us, sample_nv, sample_row0, kv_start=[slot[(u.sample, u.branch)] for u in us],
+                                                S=plan_full.S)
+            return sub_plans[key]
 
         for i, t in enumerate(timesteps.tolist()):
             if max_steps is not None and i >= max_steps:
@@ -501,21 +536,38 @@ class Bagel:
             ts_, is_ = (cfg_text_scale, cfg_img_scale) if active else (1.0, 1.0)
             full = active and use_text
             plan, ex = (plan_full, ex_full) if full else (plan_cond, ex_cond)
-            tstep = None
-            if schedules is not None:
+            if schedules is None:
+                vloc = eng.forward_gen(plan, x_bf16, temb_table[i], text_rows(plan)) if plan is not None else None
+            else:
                 active_br = [0] + ([1] if full else []) + ([2] if (full and use_img and not img_is_cond) else [])
-                kinds = {schedules[b].advance() for b in active_br}
-                counts = {schedules[b].n_factors for b in active_br}
-                if len(kinds) != 1 or len(counts) != 1:
-                    raise NotImplementedError("TaylorSeer with CFG branches that start after step 0 (their skip schedules "
-                                              "differ from the cond branch's) is not supported")
-                sch = schedules[0]
+                for b in active_br:
+                    schedules[b].advance()
+                vloc = None
                 if plan is not None:
-                    tstep = TaylorStep(kind=sch.kind, factors=factors[:, :plan.Mv * d.hidden_size], n_factors=sch.n_factors,
-                                       distance=sch.distance, x=sch.x)
+                    mine = [b for b in active_br if rows_of(plan, b)[0] is not None]      # branches with a unit on this rank
+                    run = [b for b in mine if schedules[b].kind == "full"]
+                    vloc = eng._get("v_step", (plan.Mv, d.patch_latent_dim))
+                    if run:
+                        sub = plan_for(run, plan)
+                        ups = []
+                        for b in run:
+                            r0, n = rows_of(sub, b)
+                            f0 = branch_rows[b][0]
+                            ups.append(TaylorUpdate(r0, n, factors[:, f0 * d.hidden_size:(f0 + n) * d.hidden_size],
+                                                    schedules[b].n_factors, schedules[b].distance))
+                        vsub = eng.forward_gen(sub, x_bf16, temb_table[i], text_rows(sub), taylor_updates=ups)
+                        for b in run:
+                            (r0, n), (q0, _) = rows_of(sub, b), rows_of(plan, b)
+                            vloc[q0:q0 + n].copy_(vsub[r0:r0 + n])
+                    for b in mine:
+                        if schedules[b].kind == "Taylor":
+                            q0, n = rows_of(plan, b)
+                            f0 = branch_rows[b][0]
+                            v = eng.taylor_velocity(factors[:, f0 * d.hidden_size:(f0 + n) * d.hidden_size], n,
+                                                    schedules[b].n_factors, schedules[b].x)
+                            vloc[q0:q0 + n].copy_(v)
                 for b in active_br:
                     schedules[b].done()
-            vloc = eng.forward_gen(plan, x_bf16, temb_table[i], text_emb[id(plan)], taylor=tstep) if plan is not None else None
             vout = exchange_velocities(vloc, ex, d.patch_latent_dim, dev, BF16, group)
             v_cond = vout[:Nv]
             v_text = vout[Nv:2 * Nv] if full else None

@@ -98,6 +98,11 @@ EXTRA_SCENARIOS = {s.name: s for s in [
 TAYLOR_SCENARIOS = {s.name: s for s in [
     # steps 0-4 full, then one full step in three; the CFG interval ends at step 11
     Scenario("tiny_taylor", tiny_dims(2), [(128, 192)], [9], None, [9], num_timesteps=14, enable_taylorseer=True),
+    # the CFG interval opens at step 4 and closes after step 11: the text-free and image-free branches count their own
+    # steps (bagel.py:1273-1277), so in steps 5, 6, 8 they run the layers while the conditional branch is extrapolated,
+    # in step 10 it is the other way round
+    Scenario("tiny_taylor_late", tiny_dims(2), [(128, 192)], [9], [4], [9], num_timesteps=14, cfg_interval=(0.3, 0.9),
+             enable_taylorseer=True),
 ]}
 
 

@@ -164,11 +164,6 @@ def test_api_errors():
     from tests.gpu_common import gpu_model
     model = gpu_model(sc, run.sd)
     gi = dict(run.gi)
-    # TaylorSeer needs the CFG branches to start at step 0 (one skip schedule for the packed forward)
-    import dataclasses
-    late = dataclasses.replace(sc, cfg_interval=(0.0, 0.9), enable_taylorseer=True)
-    with pytest.raises(NotImplementedError, match="TaylorSeer"):
-        run_scenario_on_gpu(late, run)
     bad = dict(gi)
     bad["packed_vae_token_indexes"] = gi["packed_vae_token_indexes"].flip(0)
     with pytest.raises(NotImplementedError):
@@ -270,12 +265,15 @@ def test_inferencer_text_to_image_end_to_end():
     assert p >= 40.0
 
 
-def test_taylorseer_matches_reference():
-    """generate_image(enable_taylorseer=True): full steps 0-4, then one full step in three; skipped steps expand the
-    cached last-layer output.  Teacher-forced from the reference's per-step inputs, branch by branch."""
+@pytest.mark.parametrize("name", ["tiny_taylor", "tiny_taylor_late"])
+def test_taylorseer_matches_reference(name):
+    """generate_image(enable_taylorseer=True): a branch's first five steps are full, then one in three; skipped steps
+    expand the cached last-layer output.  Teacher-forced from the reference's per-step inputs, branch by branch.
+    In ``tiny_taylor_late`` the CFG branches start at step 4 and keep their own schedules, so some steps run the layers
+    for a subset of the branches only."""
     from tests.gpu_common import run_scenario_on_gpu
     from tests.scenarios import TAYLOR_SCENARIOS
-    sc = TAYLOR_SCENARIOS["tiny_taylor"]
+    sc = TAYLOR_SCENARIOS[name]
     g = load_golden(sc.name)
     n = sc.num_timesteps - 1
     trace = []

@@ -40,7 +40,7 @@ def _worker(rank, world, port, name, q):
 
 
 @pytest.mark.parametrize("name,world", [("tiny_batch2", 2), ("tiny_edit3", 2), ("tiny_t2i", 2), ("tiny_t2i", 3),
-                                        ("tiny_textcfg", 2), ("tiny_taylor", 2), ("tiny_batch12", 2)])
+                                        ("tiny_textcfg", 2), ("tiny_taylor", 2), ("tiny_taylor_late", 3), ("tiny_batch12", 2)])
 def test_ranks_reproduce_one(name, world):
     """tiny_t2i has cond-only steps (outside the CFG interval) in which all ranks but one own no unit at all;
     tiny_edit3 splits one image's three branches 2 + 1; tiny_textcfg has two branches per sample; tiny_batch12 packs

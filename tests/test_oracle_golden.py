@@ -67,11 +67,13 @@ def test_oracle_free_running_final_latent():
     assert cos >= 0.999 and ma <= 0.1, (ma, cos)
 
 
-def test_oracle_taylorseer_matches_reference():
-    """generate_image with enable_taylorseer=True (full steps 0-4, then one in three; skipped steps return the Taylor
-    expansion of the last layer's cached output), teacher-forced from the reference's per-step inputs."""
+@pytest.mark.parametrize("name", ["tiny_taylor", "tiny_taylor_late"])
+def test_oracle_taylorseer_matches_reference(name):
+    """generate_image with enable_taylorseer=True (a branch's first five steps full, then one in three; skipped steps
+    return the Taylor expansion of the last layer's cached output), teacher-forced from the reference's per-step
+    inputs.  ``tiny_taylor_late``: the CFG branches start at step 4 and keep their own schedules."""
     from tests.scenarios import TAYLOR_SCENARIOS
-    sc = TAYLOR_SCENARIOS["tiny_taylor"]
+    sc = TAYLOR_SCENARIOS[name]
     g = load_golden(sc.name)
     n = sc.num_timesteps - 1
     trace = []
