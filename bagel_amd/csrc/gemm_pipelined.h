@@ -27,8 +27,11 @@
 // exist because the tile count should be a whole number of 256-CU rounds: with 12288 rows, N = 3584 is
 // 2.6 rounds of 256-wide tiles but exactly 3 rounds of 224-wide ones, N = 4608 is 3.4 rounds of 256-wide
 // tiles but exactly 3 of 288-wide ones.
-template <int EPI, int BN, int WR, bool LEAD = false>
+// AMODE = A_CONV3X3 (even split only): the A rows are output pixels of an NHWC image and K runs over (tap, channel),
+// as in gemm_bf16_nt_kernel; a piece's source pixel is carried across K steps and re-derived when the tap changes.
+template <int EPI, int BN, int WR, bool LEAD = false, int AMODE = A_DENSE>
 __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
+  static_assert(AMODE == A_DENSE || !LEAD, "the gathered A operand uses the even DMA split");
   constexpr int BM = 256, NW = 8, WC = NW / WR, TM = BM / WR, TN = BN / WC, FM = TM / 16, FN = TN / 16, FH = FM / 2;
   static_assert(TN % 16 == 0 && FM % 2 == 0 && BN % 8 == 0, "wave tile must be whole 16x16 fragments");
   static_assert(EPI != EPI_SWIGLU || FN % 2 == 0, "SwiGLU pairs gate and up fragments");
@@ -52,6 +55,8 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
   // operand + the K step's offset, both uniform) + one 32-bit lane offset that is fixed for the tile, so the pieces
   // of a tile cost one register each and the K step's advance is scalar arithmetic.
   unsigned a_src[4], w_src[W_ITERS];
+  int a_oy[4], a_ox[4], conv_c0 = 0, conv_tap = -1;     // A_CONV3X3: output pixel of each piece's row; K-step state
+  const bf16* conv_src[4];
   auto set_tile_even = [&](int t) {
     int tile_m, tile_n;
     gemm_tile_of_block(p, t, tile_m, tile_n);
@@ -65,20 +70,64 @@ __global__ __launch_bounds__(512) void gemm256_pipelined_kernel(GemmParams p) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = (it * NW + wave) * 8 + piece_row;
-      a_src[it] = (unsigned)(((long)min(lm0 + row, p.M - 1) * p.lda + src_chunk * 8) * 2);
+      if constexpr (AMODE == A_DENSE) {
+        a_src[it] = (unsigned)(((long)min(lm0 + row, p.M - 1) * p.lda + src_chunk * 8) * 2);
+      } else {
+        const int grow = min(lm0 + row, p.M - 1);
+        a_oy[it] = grow / p.Wout;
+        a_ox[it] = grow - a_oy[it] * p.Wout;
+      }
     }
+    conv_tap = -1;
 #pragma unroll
     for (int it = 0; it < W_ITERS; ++it) {
       const int row = (it * NW + wave) * 8 + piece_row;
       w_src[it] = (unsigned)(((long)min(ln0 + row, p.N - 1) * p.ldw + src_chunk * 8) * 2);
     }
   };
+  auto conv_set_tap = [&](int tap) {
+    conv_tap = tap;
+    const int tap_dy = tap / 3 - 1, tap_dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      int y = a_oy[it] + tap_dy, x = a_ox[it] + tap_dx;
+      bool ok = y >= 0 && y < p.Hout && x >= 0 && x < p.Wout;
+      if (p.upsample == 1) {
+        y >>= 1;
+        x >>= 1;
+      } else if (p.upsample == 2) {
+        y = 2 * a_oy[it] + tap_dy + 1;
+        x = 2 * a_ox[it] + tap_dx + 1;
+        ok = y < p.Hin && x < p.Win;
+      }
+      conv_src[it] = ok ? p.A + ((long)y * p.Win + x) * p.Cin + src_chunk * 8 : nullptr;
+    }
+  };
   auto stage_a_even = [&](int kt) {
     char* base = smem + (kt & 1) * STAGE_BYTES;
-    const char* src = (const char*)p.A + kt * (BK * 2);
+    if constexpr (AMODE == A_DENSE) {
+      const char* src = (const char*)p.A + kt * (BK * 2);
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
-      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + a_src[it]), LDS_PTR(base + (it * NW + wave) * 1024), 16, 0, 0);
+      for (int it = 0; it < 4; ++it)
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + a_src[it]), LDS_PTR(base + (it * NW + wave) * 1024), 16, 0, 0);
+    } else {
+      // called with kt = 0, 1, 2, ... for every tile: the tap and the pieces' pixels change every Cin / 64 calls
+      if (conv_tap < 0) {
+        conv_c0 = 0;
+        conv_set_tap(0);
+      } else {
+        conv_c0 += BK;
+        if (conv_c0 >= p.Cin) {
+          conv_c0 = 0;
+          conv_set_tap(conv_tap + 1);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const bf16* src = conv_src[it] != nullptr ? conv_src[it] + conv_c0 : p.zeros + src_chunk * 8;
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(base + (it * NW + wave) * 1024), 16, 0, 0);
+      }
+    }
   };
   auto stage_w_even = [&](int kt) {
     char* base = smem + (kt & 1) * STAGE_BYTES + A_BYTES;

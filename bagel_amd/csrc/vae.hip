@@ -8,6 +8,7 @@
 // bf16 autocast does to the reference's fp32 VAE: convolutions consume and produce bf16, GroupNorm and
 // swish run in fp32 on the bf16 input and are rounded once when the next convolution casts its input.
 #include "gemm_tile.h"
+#include "gemm_pipelined.h"
 
 // -------------------------------------------------------------------------------------------------
 // conv3x3: stride 1, padding 1 (resample mode 0); the same on the nearest-2x upsampled input (mode 1);
@@ -16,6 +17,10 @@
 // nn.Conv2d calls at autoencoder.py:76,78 (ResnetBlock), :102, :114 (Upsample), :170, :248 (conv_out).
 // W is pre-arranged [Cout][ky][kx][Cin]; Cin % 64 == 0.
 // -------------------------------------------------------------------------------------------------
+// Development knob: 0 keeps every convolution on the 128 x 128 tile (A/B timing, tools/vae_bench.py).
+static int g_conv_pipelined = 1;
+extern "C" void bagel_set_conv_pipelined(int on) { g_conv_pipelined = on; }
+
 extern "C" int bagel_conv3x3_nhwc_bf16(const void* x, int Hin, int Win, int Cin, int upsample, const void* w, int Cout,
                                        const void* bias, const void* residual, void* out, const void* zero_page,
                                        void* stream) {
@@ -50,6 +55,33 @@ extern "C" int bagel_conv3x3_nhwc_bf16(const void* x, int Hin, int Win, int Cin,
                        2 * (BM + BN) * ROW_BYTES, st, p);
     BAGEL_LAUNCH_CHECK();
     return 0;
+  }
+  // Large images with 256 or 512 output channels: the software-pipelined 256 x 256 tile (persistent workgroups, one
+  // per CU) once its tiles fill the chip: 15-20 % faster there.  With 128 output channels a 256 x 128 tile of the same
+  // loop measured no faster than two 128 x 128 workgroups per CU (381 against 370 us at 1024 x 1024: half the matrix
+  // work per DMA piece), so those layers keep the small tile.  Same K order either way: same bits.
+  {
+    const int bn = Cout % 256 == 0 ? 256 : 0;
+    const long tiles = bn ? (long)((p.M + 255) / 256) * (Cout / bn) : 0;
+    const int cus = bagel_cu_count() >= 8 ? bagel_cu_count() / 8 * 8 : 256;
+    if (g_conv_pipelined && tiles >= cus) {
+      p.tiles_m = (p.M + 255) / 256;
+      p.tiles_n = Cout / bn;
+      const dim3 grid((unsigned)(tiles < cus ? tiles : cus)), block(512);
+      const size_t lds = 2 * (256 + bn) * ROW_BYTES;
+#define LAUNCH_PIPE(EPI, BN_, WR_)                                                                   \
+      do {                                                                                           \
+        auto k = gemm256_pipelined_kernel<EPI, BN_, WR_, false, A_CONV3X3>;                          \
+        static BagelLdsAllowed allowed;                                                              \
+        bagel_allow_lds(allowed, (const void*)k, (int)lds);                                          \
+        hipLaunchKernelGGL(k, grid, block, lds, st, p);                                              \
+      } while (0)
+      if (residual) LAUNCH_PIPE(EPI_BIAS_RESIDUAL, 256, 2);
+      else LAUNCH_PIPE(EPI_BIAS, 256, 2);
+#undef LAUNCH_PIPE
+      BAGEL_LAUNCH_CHECK();
+      return 0;
+    }
   }
   constexpr int BM = 128, BN = 128;
   p.tiles_m = (p.M + BM - 1) / BM;
