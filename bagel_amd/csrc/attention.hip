@@ -333,12 +333,289 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 3) void attention_kernel(AttnParams
 #endif
 }
 
+// The same algorithm on v_mfma_f32_16x16x32_bf16 (head_dim 128): twice the matrix instructions of half the
+// length.  Under the matrix load of this loop the chip holds a higher clock on the 16 x 16 shape, so cycles per
+// FLOP do not decide between the two forms; they are compared by wall time on random data.
+//     S^T block (16 keys x 16 queries): lane (i = lane & 15, g = lane >> 4) holds query i, MFMA rows 4g .. 4g+3
+//     P^T as B operand of O^T += Vt . P^T over a 32-key step: lane (i, g) must hold keys 8g .. 8g+7 of the step
+// so MFMA row 4g + e of the step's key block b (b = 0, 1) is fed key 8g + 4b + e: the two blocks' accumulators,
+// rounded to bf16, are the B operand in natural key order.  A wave owns 32 query rows as two 16-query blocks.
+// K tile swizzle: chunk ^ (MFMA row index of the key), which makes every ds_read_b128 lane group hit 16 distinct
+// slots; a wave stages the four 1-KiB pieces whose rows share that index's high bits, so one lane offset serves
+// them all.  The Vt tile keeps the layout of the 32 x 32 form.
+template <bool DEEP>
+__global__ __launch_bounds__(256, DEEP ? 2 : 3) void attention16_kernel(AttnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int HD = 128;
+  constexpr int KS = HD / 32;        // k steps of the score product
+  constexpr int DB = HD / 16;        // 16-wide d blocks of the output
+  constexpr int K_BYTES = KT * HD * 2, V_BYTES = HD * KT * 2, STAGE = K_BYTES + V_BYTES;
+  constexpr int K_IT = 4, V_IT = 4;  // 1-KiB pieces per wave and tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int rep = p.Hq / p.Hkv;
+  const int nwg = p.n_tiles * p.Hq;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, loc = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int kvh = wg / (p.n_tiles * rep);
+  const int rem = wg - kvh * p.n_tiles * rep;
+  const int tile_idx = rem / rep;
+  const int head = kvh * rep + rem % rep;
+  const AttnTile t = p.tiles[tile_idx];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, g = lane >> 4;
+
+  // ---- Q fragments (B operand of S^T): lane (i, g) holds Q[row i of block qb][32 ks + 8 g .. +8)
+  bf16x8 qf[2][KS];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = min(wave * 32 + 16 * qb + i16, t.n_rows - 1);
+    const bf16* qp = p.Q + ((long)(t.q_row0 + qrow) * p.Hq + head) * HD + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[qb][ks] = *(const bf16x8*)(qp + 32 * ks);
+  }
+
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.K + ((long)kvh * p.S + t.kv_start) * HD), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.Vt + (long)kvh * HD * p.S + t.kv_start), 0, 0x7fffffff, 0x00020000);
+  // K piece q = key rows 4q .. 4q+3; the swizzle of row r is ((r >> 3) & 3) << 2 | (r & 3), whose high bits are
+  // (q >> 1) & 3: wave w takes pieces 2w, 2w+1, 2w+8, 2w+9.
+  const int k_voff = ((lane >> 4) * HD + (((lane & 15) ^ (wave << 2 | (lane >> 4))) * 8)) * 2;
+  const int vrow0 = wave * 8 + (lane >> 3);
+  const int v_voff = (int)(((long)vrow0 * p.S + (((lane & 7) ^ ((vrow0 >> 1) & 7)) * 8)) * 2);
+  const int v_piece = (int)(64 * p.S);
+  auto stage_k_piece = [&](int kt, int buf, int it) {
+    const int q = 2 * wave + (it & 1) + 8 * (it >> 1);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, LDS_PTR(smem + buf * STAGE + q * 1024), 16, k_voff,
+                                             kt * (KT * HD * 2) + q * 1024, 0, 0);
+  };
+  auto stage_v_piece = [&](int kt, int buf, int it) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, LDS_PTR(smem + buf * STAGE + K_BYTES + (it * 4 + wave) * 1024), 16,
+                                             v_voff, kt * (KT * 2) + it * v_piece, 0, 0);
+  };
+  auto stage_k = [&](int kt, int buf) {
+#pragma unroll
+    for (int it = 0; it < K_IT; ++it) stage_k_piece(kt, buf, it);
+  };
+  auto stage_v = [&](int kt, int buf) {
+#pragma unroll
+    for (int it = 0; it < V_IT; ++it) stage_v_piece(kt, buf, it);
+  };
+
+  // ---- fragment read offsets
+  // K block kb = 2 j + b of the tile: MFMA row i is key 32 j + 8 (i >> 2) + 4 b + (i & 3); chunk 4 ks + g of that row
+  // sits at (4 ks + g) ^ i, i.e. at byte (row base | (g ^ i) << 4) ^ (ks << 6).
+  const int k_a0 = (8 * (i16 >> 2) + (i16 & 3)) * (HD * 2) + ((g ^ i16) << 4);
+  // Vt: row d = 16 db + i; chunk 4 j + g of the row at (row base | (g ^ swizzle) << 4) ^ (j << 6)
+  const int v_a0 = i16 * (KT * 2) + ((g ^ ((i16 >> 1) & 7)) << 4);
+
+  f32x4 o_acc[2][DB];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o_acc[qb][d][r] = 0.f;
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+  const bool causal = t.causal_base >= 0;
+  const int kv_len = causal ? min(t.kv_len, t.causal_base + t.n_rows) : t.kv_len;
+  int row_limit[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) row_limit[qb] = causal ? t.causal_base + wave * 32 + 16 * qb + i16 + 1 : kv_len;
+  const int n_kt = (kv_len + KT - 1) / KT;
+  stage_k(0, 0);
+  if constexpr (DEEP) stage_v(0, 0);
+  if (wave * 32 >= t.n_rows) {
+    // a wave without query rows only moves its share of the tiles and keeps the barrier count
+    for (int kt = 0; kt < n_kt; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if constexpr (DEEP) {
+        if (kt + 1 < n_kt) {
+          stage_k(kt + 1, (kt + 1) & 1);
+          stage_v(kt + 1, (kt + 1) & 1);
+        }
+      } else {
+        stage_v(kt, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < n_kt) stage_k(kt + 1, 0);
+      }
+    }
+    return;
+  }
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+  for (int kt = 0; kt < n_kt; ++kt) {
+    const char* kb = smem + (DEEP ? (kt & 1) * STAGE : 0);
+    const char* vb = kb + K_BYTES;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // S^T: 4 key blocks x 2 query blocks, 4 k steps each; the 16 key fragments go through a ring, each feeding the
+    // two query blocks' products
+    f32x4 s[2][4];
+    int k_a = k_a0;
+    asm volatile("" : "+v"(k_a));
+    constexpr int RING = ATTN_QK_RING;
+    bf16x8 kf[RING];
+    auto kread = [&](int i) {
+      const int blk = i / KS;
+      return *(const bf16x8*)(kb + (32 * (blk >> 1) + 4 * (blk & 1)) * (HD * 2) + (k_a ^ ((i % KS) << 6)));
+    };
+#pragma unroll
+    for (int i = 0; i < RING; ++i) kf[i] = kread(i);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DEEP) {
+      if (kt + 1 < n_kt) {
+        stage_k(kt + 1, (kt + 1) & 1);
+        stage_v(kt + 1, (kt + 1) & 1);
+      }
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[qb][b][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4 * KS; ++i) {
+      s[0][i / KS] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i % RING], qf[0][i % KS], s[0][i / KS], 0, 0, 0);
+      s[1][i / KS] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i % RING], qf[1][i % KS], s[1][i / KS], 0, 0, 0);
+      if (i + RING < 4 * KS) kf[i % RING] = kread(i + RING);
+      if constexpr (!DEEP)
+        if (i % 2 == 1 && i / 2 < V_IT) stage_v_piece(kt, 0, i / 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int key0 = kt * KT;
+    const bool tail = key0 + KT > (causal ? t.causal_base + wave * 32 + 1 : kv_len);  // wave-uniform
+    if (tail) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = key0 + 32 * (b >> 1) + 8 * g + 4 * (b & 1) + r;
+            s[qb][b][r] = key < row_limit[qb] ? s[qb][b][r] : -INFINITY;
+          }
+    }
+    // wait out the MFMA-result read hazard before inline assembly reads the scores
+    asm volatile("s_nop 7\n\ts_nop 3"
+                 : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][2]), "+v"(s[0][3]), "+v"(s[1][0]), "+v"(s[1][1]),
+                   "+v"(s[1][2]), "+v"(s[1][3]));
+    float mx[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float m = vmax3(s[qb][0][0], s[qb][0][1], s[qb][0][2]);
+      m = vmax3(m, s[qb][0][3], s[qb][1][0]);
+      m = vmax3(m, s[qb][1][1], s[qb][1][2]);
+      m = vmax3(m, s[qb][1][3], s[qb][2][0]);
+      m = vmax3(m, s[qb][2][1], s[qb][2][2]);
+      m = vmax3(m, s[qb][2][3], s[qb][3][0]);
+      m = vmax3(m, s[qb][3][1], s[qb][3][2]);
+      m = vmax2(m, s[qb][3][3]);
+      // the row's other keys are on lanes l ^ 16, l ^ 32, l ^ 48: two swaps
+      const u32x2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+      m = vmax2(__uint_as_float(a[0]), __uint_as_float(a[1]));
+      const u32x2 c = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+      mx[qb] = vmax2(__uint_as_float(c[0]), __uint_as_float(c[1])) * p.scale_log2;
+    }
+    if (__any(mx[0] > m_run[0] || mx[1] > m_run[1])) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const float m_new = fmaxf(m_run[qb], mx[qb]);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - (m_new == -INFINITY ? 0.f : m_new));
+        m_run[qb] = m_new;
+        l_run[qb] *= alpha;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o_acc[qb][d][r] *= alpha;
+      }
+    }
+    if constexpr (!DEEP) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < n_kt) stage_k(kt + 1, 0);
+    }
+    int v_a = v_a0;
+    asm volatile("" : "+v"(v_a));
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const float neg_m = m_run[qb] == -INFINITY ? 0.f : -m_run[qb];
+      float psum = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][b][r], p.scale_log2, neg_m));
+          s[qb][b][r] = e;
+          psum += e;
+        }
+      l_run[qb] += psum;
+    }
+
+    // O^T += Vt . P^T : 2 k steps of 32 keys, 8 d blocks, 2 query blocks
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bf16x8 pf[2];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          pf[qb][e] = (bf16)s[qb][2 * j][e];
+          pf[qb][4 + e] = (bf16)s[qb][2 * j + 1][e];
+        }
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const bf16x8 vf = *(const bf16x8*)(vb + d * 16 * (KT * 2) + (v_a ^ (j << 6)));
+        o_acc[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0], o_acc[0][d], 0, 0, 0);
+        o_acc[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1], o_acc[1][d], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: lane holds query row i of each block, d = 16 db + 4 g + e
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float l_tot = l_run[qb];
+    l_tot += __shfl_xor(l_tot, 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int row = wave * 32 + 16 * qb + i16;
+    if (row < t.n_rows) {
+      bf16* op = p.O + ((long)(t.q_row0 + row) * p.Hq + head) * HD + 4 * g;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        bf16x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = (bf16)(o_acc[qb][d][e] * inv);
+        *(bf16x4*)(op + d * 16) = o4;
+      }
+    }
+  }
+#endif
+}
+
 extern "C" int bagel_varlen_attention_scaled_bf16(const void* Q, const void* K, const void* Vt, void* O,
                                                   const void* tiles, int n_tiles, int Hq, int Hkv, int head_dim,
                                                   long S, float softmax_scale, void* stream);
 // Development knob: -1 automatic (by launch size), 0 / 1 force the throughput / latency form of the kernel.
 static int g_attn_deep = -1;
 extern "C" void bagel_set_attn_deep(int v) { g_attn_deep = v; }
+// Development knob: 1 = the 16 x 16 x 32 MFMA form of the head_dim-128 kernel, 0 = the 32 x 32 x 16 form.
+#ifndef ATTN_MFMA16
+#define ATTN_MFMA16 0
+#endif
+static int g_attn_mfma16 = ATTN_MFMA16;
+extern "C" void bagel_set_attn_mfma16(int v) { g_attn_mfma16 = v; }
 
 extern "C" int bagel_varlen_attention_bf16(const void* Q, const void* K, const void* Vt, void* O,
                                            const void* tiles, int n_tiles, int Hq, int Hkv, int head_dim,
@@ -371,7 +648,12 @@ extern "C" int bagel_varlen_attention_scaled_bf16(const void* Q, const void* K, 
   if (head_dim == 128) {
     static BagelLdsAllowed allowed;
     bagel_allow_lds(allowed, (const void*)attention_kernel<128, true>, 2 * KT * 128 * 2 * 2);
-    if (deep) hipLaunchKernelGGL((attention_kernel<128, true>), dim3(n_tiles * Hq), dim3(256), lds, (hipStream_t)stream, p);
+    static BagelLdsAllowed allowed16;
+    bagel_allow_lds(allowed16, (const void*)attention16_kernel<true>, 2 * KT * 128 * 2 * 2);
+    if (g_attn_mfma16) {
+      if (deep) hipLaunchKernelGGL((attention16_kernel<true>), dim3(n_tiles * Hq), dim3(256), lds, (hipStream_t)stream, p);
+      else hipLaunchKernelGGL((attention16_kernel<false>), dim3(n_tiles * Hq), dim3(256), lds, (hipStream_t)stream, p);
+    } else if (deep) hipLaunchKernelGGL((attention_kernel<128, true>), dim3(n_tiles * Hq), dim3(256), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attention_kernel<128, false>), dim3(n_tiles * Hq), dim3(256), lds, (hipStream_t)stream, p);
   } else {
     if (deep) hipLaunchKernelGGL((attention_kernel<64, true>), dim3(n_tiles * Hq), dim3(256), lds, (hipStream_t)stream, p);

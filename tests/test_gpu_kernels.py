@@ -401,10 +401,11 @@ def test_qk_norm_rope_kv(und_rounding):
     assert float(Kws.cpu()[:, untouched].abs().max()) == 0.0 and float(Vt.cpu()[:, :, untouched].abs().max()) == 0.0
 
 
-def _attention_case(q_lens, ctx_lens, Hq, Hkv, seed, spike=False, causal=False, D=128, form=-1):
+def _attention_case(q_lens, ctx_lens, Hq, Hkv, seed, spike=False, causal=False, D=128, form=-1, mfma16=0):
     """Build Q and a KV workspace with per-sample [context | queries] ranges and the tile table.
     ``form``: -1 lets the launcher choose by launch size, 0 / 1 force the kernel's throughput form (single LDS
-    buffers, three workgroups per CU) / latency form (double buffers)."""
+    buffers, three workgroups per CU) / latency form (double buffers).  ``mfma16``: 1 runs the head_dim-128 kernel
+    built on the 16 x 16 x 32 matrix instruction (a measured alternative, not the default)."""
     k = _K()
     g = torch.Generator().manual_seed(seed)
     M = sum(q_lens)
@@ -426,11 +427,13 @@ def _attention_case(q_lens, ctx_lens, Hq, Hkv, seed, spike=False, causal=False, 
         r0 += n
     Od = torch.full((M, Hq, D), float("nan"), dtype=BF16, device=DEV)
     k.lib().bagel_set_attn_deep(form)
+    k.lib().bagel_set_attn_mfma16(mfma16)
     try:
         k.varlen_attention(Q.to(DEV), Kf.to(DEV), Vf.permute(0, 2, 1).contiguous().to(DEV), Od,
                            torch.tensor(tiles, dtype=torch.int32).to(DEV), len(tiles), Hq, Hkv, D, S)
     finally:
         k.lib().bagel_set_attn_deep(-1)
+        k.lib().bagel_set_attn_mfma16(0)
     kk = torch.cat([Kf[:, st:st + kl].permute(1, 0, 2) for st, kl in zip(starts, kv_lens)])
     vv = torch.cat([Vf[:, st:st + kl].permute(1, 0, 2) for st, kl in zip(starts, kv_lens)])
     ref = O.varlen_attention(Q, kk, vv, q_lens, kv_lens, causal=causal)
@@ -570,6 +573,19 @@ def test_varlen_attention_forms_agree():
     """Both forms walk the same tiles in the same order: identical bits."""
     a, _ = _attention_case([66, 130], [7, 300], 4, 2, seed=44, form=0)
     b, _ = _attention_case([66, 130], [7, 300], 4, 2, seed=44, form=1)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("q_lens,ctx_lens,Hq,Hkv,causal", [
+    ([128], [0], 2, 1, False), ([2], [62], 2, 1, False), ([66, 130], [7, 300], 4, 2, False), ([258], [34], 14, 2, False),
+    ([1026], [4100], 7, 1, False), ([5, 200], [0, 77], 4, 2, True), ([300], [130], 14, 2, True)])
+def test_varlen_attention_mfma16_variant(q_lens, ctx_lens, Hq, Hkv, causal):
+    """The 16 x 16 x 32 build of the kernel (selected only by its development knob): same bar as the default, and
+    its two forms agree bit for bit."""
+    a, ref = _attention_case(q_lens, ctx_lens, Hq, Hkv, seed=45, causal=causal, form=0, mfma16=1)
+    b, _ = _attention_case(q_lens, ctx_lens, Hq, Hkv, seed=45, causal=causal, form=1, mfma16=1)
+    assert not torch.isnan(a.float()).any()
+    _close(a, ref, ulps=2.0, what="attention, 16x16x32 form")
     assert torch.equal(a, b)
 
 
