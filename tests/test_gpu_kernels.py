@@ -180,6 +180,8 @@ def test_gemm_random_shapes():
     k = _K()
     rnd = random.Random(5)
     for case in range(int(os.environ.get("BAGEL_FUZZ_CASES", 30))):      # a longer soak: BAGEL_FUZZ_CASES=500
+        if case and case % 100 == 0:
+            print(f"  random GEMM shapes: {case}", flush=True)
         M = rnd.choice([1, 7, 130, 255, 257, 1000, 4098, 6001, 12294])
         Kd = 64 * rnd.randint(1, 40)
         epi = rnd.choice(["bias", "residual", "swiglu", "bias_residual", "f32", "bias_gelu"])
@@ -455,6 +457,8 @@ def test_varlen_attention_random_cases():
     import random
     rnd = random.Random(11)
     for case in range(int(os.environ.get("BAGEL_FUZZ_CASES", 24))):
+        if case and case % 100 == 0:
+            print(f"  random attention cases: {case}", flush=True)
         n = rnd.randint(1, 4)
         q_lens = [rnd.choice([1, 2, 31, 64, 65, 127, 128, 129, 200, 300]) for _ in range(n)]
         ctx_lens = [rnd.choice([0, 1, 7, 63, 64, 65, 130, 500]) for _ in range(n)]

@@ -129,6 +129,8 @@ def test_random_scenarios_match_cpu_checker():
     rnd = random.Random(2024)
     n_cases = int(os.environ.get("BAGEL_FUZZ_SCENARIOS", 4))
     for case in range(n_cases):
+        if case and case % 50 == 0:
+            print(f"  random scenarios: {case} / {n_cases}", flush=True)
         B = rnd.randint(1, 3)
         images = [(16 * rnd.randint(2, 14), 16 * rnd.randint(2, 14)) for _ in range(B)]
         lens = lambda: [rnd.choice([1, 2, 5, 31, 62, 63, 64, 65, 130, 200]) for _ in range(B)]   # noqa: E731

@@ -81,6 +81,8 @@ def test_random_decode_batches_match_cpu_checker():
     rnd = random.Random(77)
     n_cases = int(os.environ.get("BAGEL_FUZZ_DECODE", 5))
     for case in range(n_cases):
+        if case and case % 25 == 0:
+            print(f"  random decode batches: {case} / {n_cases}", flush=True)
         n = rnd.choice([1, 2, 3, 4, 5, 7, 12, 16, 17, 24])
         tc = TextCase(f"random{case}", tiny_dims(rnd.randint(1, 3)), [rnd.choice([1, 3, 30, 62, 63, 64, 65, 140]) for _ in range(n)],
                       rnd.randint(3, 9), weight_seed=case % 4)

@@ -121,6 +121,8 @@ def test_decode_random_latent_sizes_match_cpu_checker():
     rnd = random.Random(3)
     n_cases = int(os.environ.get("BAGEL_FUZZ_VAE", 3))
     for case in range(n_cases):
+        if case and case % 10 == 0:
+            print(f"  random VAE sizes: {case} / {n_cases}", flush=True)
         h, w = 2 * rnd.randint(1, 10), 2 * rnd.randint(1, 10)     # BAGEL latents are 2 x 2-patchified: even sides
         z = _rand((1, vd.z_channels, h, w), 1.0, 300 + case)
         img = ae.decode(z).float().cpu()
