@@ -173,4 +173,9 @@ IMAGE_CTX_CASES = {c.name: c for c in [
     # reduced depth, two images of different size packed (20 x 28 and 31 x 12 patches), tiny language model behind it
     ImageCtxCase("ctx_vit_so400m", dataclasses.replace(tiny_dims(2), vit=ViTDims(num_layers=3)), [4, 6], None,
                  [(280, 392), (434, 168)]),
+    # the editing path at BAGEL-7B width (2 layers) behind the so400m-wide tower (2 layers) and the full FLUX encoder:
+    # a 194-token VAE context, a 142-token ViT context, a 22-token instruction, three CFG branches with three
+    # different contexts (358 / 336 / 22 tokens) on a 256 x 192 output (sizes kept small for the fixture file)
+    ImageCtxCase("edit_w7b", dataclasses.replace(width7b_dims(2), vit=ViTDims(num_layers=2)), None, [(192, 256)],
+                 [(140, 196)], edit_prompt=[20], out_image=(256, 192), num_timesteps=3),
 ]}

@@ -1,6 +1,7 @@
 """The CPU checker's image-context paths (SigLIP tower + connector prefill, VAE encode + VAE-token prefill, the
 editing path's generation) against golden vectors captured from the reference."""
 import copy
+import math
 
 import pytest
 import torch
@@ -124,6 +125,11 @@ def test_oracle_image_context_matches_reference(name):
             with torch.no_grad():
                 vt, (vc, vx, vm) = edit_flow(ic, sd, out, g[f"edit.step{i}.x_t"], ts[i])
             for k, v in (("v_cond", vc), ("v_text", vx), ("v_img", vm), ("v_t", vt)):
-                ma, cos = metrics(v, g[f"edit.step{i}.{k}"])
-                # CFG amplifies branch differences by up to (2 s_text - 1)(2 s_img - 1) = 21
-                assert cos >= 0.999 and ma <= (2e-2 if k != "v_t" else 0.2), (i, k, ma, cos)
+                ref = g[f"edit.step{i}.{k}"]
+                ma, cos = metrics(v, ref)
+                # 2e-2, or two bf16 ulps at the tensor's top magnitude where that is more (7B-width velocities reach
+                # |v| > 4, where one ulp is 0.031); CFG amplifies branch differences by up to
+                # (2 s_text - 1)(2 s_img - 1) = 21
+                ulp = 2.0 ** (math.floor(math.log2(max(float(ref.float().abs().max()), 1e-30))) - 7)
+                bound = max(2e-2, 2 * ulp)
+                assert cos >= 0.999 and ma <= (bound if k != "v_t" else 10 * bound), (i, k, ma, cos)
