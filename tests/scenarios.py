@@ -123,6 +123,9 @@ TEXT_CASES = {c.name: c for c in [
     TextCase("text_tiny_b1", tiny_dims(2), [7], 12),
     TextCase("text_tiny_b2", tiny_dims(3), [12, 40], 10, weight_seed=3),
     TextCase("text_gqa7", _small_gqa(), [33], 8, weight_seed=1),
+    # BAGEL-7B width (2 layers): the decode step's one-launch attention and GEMV / weight-streaming projections at their
+    # real reduction lengths (3584, 18944), two samples with prompts on both sides of a 64-slot boundary
+    TextCase("text_w7b", width7b_dims(2), [34, 70], 10, weight_seed=2),
 ]}
 
 
