@@ -179,6 +179,10 @@ IMAGE_CTX_CASES = {c.name: c for c in [
     # the editing path at BAGEL-7B width (2 layers) behind the so400m-wide tower (2 layers) and the full FLUX encoder:
     # a 194-token VAE context, a 142-token ViT context, a 22-token instruction, three CFG branches with three
     # different contexts (358 / 336 / 22 tokens) on a 256 x 192 output (sizes kept small for the fixture file)
+    # mixed-resolution context building at BAGEL-7B width: two samples, each a prompt, a VAE-encoded image and a
+    # ViT-encoded image, all of different sizes, packed into the varlen prefills
+    ImageCtxCase("ctx_mixed_w7b", dataclasses.replace(width7b_dims(2), vit=ViTDims(num_layers=2)), [6, 11],
+                 [(128, 192), (192, 128)], [(112, 168), (196, 140)]),
     ImageCtxCase("edit_w7b", dataclasses.replace(width7b_dims(2), vit=ViTDims(num_layers=2)), None, [(192, 256)],
                  [(140, 196)], edit_prompt=[20], out_image=(256, 192), num_timesteps=3),
 ]}
