@@ -9,7 +9,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests.helpers import OracleRun, load_golden, have_golden, metrics, check_velocity, scenario_state_dict  # noqa: E402
+from tests.helpers import (OracleRun, load_golden, have_golden, metrics, check_velocity, scenario_state_dict,  # noqa: E402
+                           parity_stats, mean_slack, EXACT_RATIO_MEAN, REF_RATIO_MAX)
 from tests.scenarios import SCENARIOS  # noqa: E402
 from tests.gpu_common import run_scenario_on_gpu  # noqa: E402
 
@@ -145,11 +146,14 @@ def test_random_scenarios_match_cpu_checker():
         what = f"case {case}: {images} cond {cond} text {text} img {img} L={sc.dims.num_layers} scales " \
                f"{sc.cfg_text_scale}/{sc.cfg_img_scale} {sc.cfg_interval} {sc.cfg_renorm_type} min {sc.cfg_renorm_min}"
         run = OracleRun(sc)
+        exact_run = OracleRun(sc, sd=run.sd, exact=True)
         otrace, trace = [], []
         run.generate(trace=otrace, max_steps=3)
         run_scenario_on_gpu(sc, run, trace=trace, max_steps=3, teacher_x=[r["x_t"] for r in otrace])
         assert len(trace) == len(otrace) == 3, what
         for i, (a, b) in enumerate(zip(trace, otrace)):
+            vt_e, (vc_e, vx_e, vm_e) = exact_run.step(i, b["x_t"])
+            exact = {"v_cond": vc_e, "v_text": vx_e, "v_img": vm_e, "v_t": vt_e}
             for key in ("v_cond", "v_text", "v_img", "v_t"):
                 if b.get(key) is None or key not in a:
                     continue
@@ -157,6 +161,16 @@ def test_random_scenarios_match_cpu_checker():
                 # a combined velocity amplifies the branches' rounding differences by the CFG scales
                 amp = 1.0 if key != "v_t" else max(sc.cfg_text_scale, 1.0) * max(sc.cfg_img_scale, 1.0) * 2.0
                 assert cos >= (0.999 if key != "v_t" else 0.995) and ma <= 4e-2 * amp, (what, i, key, ma, cos)
+                # and relative to the checker's own rounding: the HIP path may be no further from exact (fp32, no
+                # rounding points) arithmetic on the same inputs than the bf16 checker is, up to sampling noise on
+                # the mean and a rounding that went the other way in the top binade on the maximum
+                if exact[key] is None:
+                    continue
+                st = parity_stats(a[key], b[key], exact[key])
+                assert st["hip_vs_exact_mean"] <= (EXACT_RATIO_MEAN + mean_slack(st)) * st["ref_vs_exact_mean"] + 1e-6, \
+                    (what, i, key, "mean distance to exact", st["hip_vs_exact_mean"], st["ref_vs_exact_mean"])
+                assert st["hip_vs_exact_max"] <= REF_RATIO_MAX * st["ref_vs_exact_max"] + 1e-6, \
+                    (what, i, key, "max distance to exact", st["hip_vs_exact_max"], st["ref_vs_exact_max"])
     print(f"{n_cases} random scenarios agree with the CPU checker")
 
 
