@@ -40,7 +40,10 @@ __device__ __forceinline__ void gemm_tile_of_block(const GemmParams& p, int bloc
     const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, loc = wg >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  constexpr int GROUP_M = 8;
+#ifndef GEMM_GROUP_M
+#define GEMM_GROUP_M 8   // M-tiles per band; a diagnostic build may change it (the walk's fabric traffic is measured per value)
+#endif
+  constexpr int GROUP_M = GEMM_GROUP_M;
   const int band = wg / (GROUP_M * p.tiles_n);
   const int band_first = band * GROUP_M;
   const int band_rows = min(p.tiles_m - band_first, GROUP_M);
