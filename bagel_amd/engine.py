@@ -11,7 +11,7 @@ All arithmetic happens in libbagel_hip.so; torch allocates buffers and builds sm
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
 import torch

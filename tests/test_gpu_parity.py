@@ -255,7 +255,6 @@ def test_inferencer_text_to_image_end_to_end():
     from bagel_amd.weights import make_llm_state_dict, make_vae_decoder_state_dict
     from tests.gpu_common import gpu_model
     from tests.scenarios import NEW_TOKEN_IDS
-    from tests.test_oracle_vae import psnr
     from oracle import bagel_oracle as O
     import numpy as np
     sc = SCENARIOS["tiny_t2i"]
