@@ -13,7 +13,6 @@ import json
 import os
 from typing import Dict, List, Tuple, Union
 
-import torch
 from PIL import Image
 from safetensors import safe_open
 

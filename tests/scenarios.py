@@ -7,12 +7,12 @@ tensors) is regenerated from these numbers on whichever machine runs the test.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
 import dataclasses
 
-from bagel_amd.config import BagelDims, ViTDims, tiny_dims, width7b_dims, BAGEL_0P5B
+from bagel_amd.config import BagelDims, ViTDims, tiny_dims, width7b_dims
 
 NEW_TOKEN_IDS = dict(bos_token_id=1, eos_token_id=2, start_of_image=3, end_of_image=4)
 
