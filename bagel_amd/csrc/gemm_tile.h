@@ -295,6 +295,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmParams p)
         }
       }
     }
+#ifdef BAGEL_DIAG_CONV_A_ONCE   // timing only (wrong results): the A tile is fetched for the first tap alone
+    if (AMODE == A_CONV3X3 && conv_tap != 0) goto a_done;
+#endif
 #pragma unroll
     for (int it = 0; it < A_ITERS; ++it) {
       const bf16* src;
@@ -302,6 +305,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmParams p)
       else src = conv_src[it] != nullptr ? conv_src[it] + conv_c0 : p.zeros + src_chunk * 8;
       __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(base + (it * NW + wave) * 1024), 16, 0, 0);
     }
+#ifdef BAGEL_DIAG_CONV_A_ONCE
+  a_done:;
+#endif
 #pragma unroll
     for (int it = 0; it < W_ITERS; ++it)
       __builtin_amdgcn_global_load_lds(GLOBAL_PTR(w_src[it] + koff),
