@@ -72,13 +72,13 @@ def synthetic_context(dims, n_samples, ctx_len, device, seed):
 
 def cpu_baseline(dims_full, resolution, num_timesteps):
     """The CPU checker (oracle/, a port of the reference's PyTorch path) timed on this host's cores on a
-    bounded sample: one three-branch CFG flow step at BAGEL-7B width, 2 of 28 layers, same resolution.
+    bounded sample: one three-branch CFG flow step at BAGEL-7B width, 4 of 28 layers, same resolution (10-15 s).
     Scaled to images/sec by layers and by the 131/3 step-equivalents per image."""
     import dataclasses
     from bagel_amd.config import width7b_dims
     from tests.helpers import OracleRun
     from tests.scenarios import Scenario
-    layers = 2
+    layers = 4
     sc = Scenario("cpu_baseline", width7b_dims(layers), [(resolution, resolution)], [32], None, [32],
                   num_timesteps=num_timesteps)
     run = OracleRun(sc)
